@@ -1,0 +1,127 @@
+/*
+ * smallpt_mi355x.h -- C-ABI of the MI355X-native path tracer (libsmallpt_mi355x.so).
+ *
+ * This is the drop-in boundary for the reference's render hot path.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference tree):
+ *
+ *   reference seam                                             replaced by
+ *   ---------------------------------------------------------  ---------------------------------
+ *   Sphere spheres[] / Material (smallpt.cpp:31-50,            spt_set_scene()
+ *     scene.h:66-92) + Intersector::addTriangleMesh/build
+ *     (smallpt.cpp:489-530: "upload the scene to the device")
+ *   cam / cx / cy of cpuRender (smallpt.cpp:277-279)            spt_camera_smallpt()
+ *   int cpuRender(argc, argv) (smallpt.cpp:269-379): the        spt_render()           (host image)
+ *     offline render; and Vector<float3> Renderer::render(..)   spt_render_rows_device() (row band,
+ *     (smallpt.cpp:679-680,692-814), sole caller :922             device-resident, async)
+ *   Intersector::traceRays + shadePaths per bounce              inside the megakernel; not exposed
+ *     (smallpt.cpp:553-587,154-267)
+ *   "Elapsed time" stderr line (smallpt.cpp:371-373,809-811)    spt_stats
+ *   CHK_PRIME / rtpContextGetLastErrorString                    int status + spt_last_error()
+ *     (smallpt.cpp:381-393)
+ *
+ * Conventions kept from the reference: the image is row-major w*h packed float3 (12 B/pixel), row 0
+ * is the BOTTOM row (camera cy is +y; flipY happens only before the PPM, smallpt.cpp:125-134,375),
+ * spp = 4 * samps_per_cell (2x2 jitter cells, smallpt.cpp:285-286).  With SPT_FLAG_NORMALISE the
+ * image is divided by spp like cpuRender (:358-361); without it the un-normalised SUM is returned
+ * like Renderer::render (:790,:813) for a caller that accumulates frames (:924-936) and weights
+ * at display time (:957-962, glutils.cpp:230-256).
+ *
+ * All functions return 0 on success, non-zero on error (message via spt_last_error).  No C++
+ * types, no exceptions cross this boundary.  A context is bound to one HIP device and is not
+ * thread-safe; use one context per device (one process per GPU under torch.distributed, or one
+ * host thread per device).
+ */
+#ifndef SMALLPT_MI355X_H
+#define SMALLPT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPT_API_VERSION 1
+
+typedef struct spt_ctx spt_ctx;
+
+/* Refl_t, scene.h:64 */
+enum { SPT_DIFF = 0, SPT_SPEC = 1, SPT_REFR = 2 };
+
+/* 48-byte POD; field order = Sphere constructor, scene.h:91 (radius, center, emission, color, refl),
+ * regrouped so that {center, radius} is one 16-byte load. */
+typedef struct spt_sphere {
+    float    center[3];
+    float    radius;
+    float    emission[3];
+    float    color[3];
+    int32_t  refl;
+    uint32_t pad;
+} spt_sphere;
+
+/* smallpt camera (smallpt.cpp:277-279,331-333): d = cx*ax + cy*ay + dir; ray = (origin + d*push, normalize(d)) */
+typedef struct spt_camera {
+    float origin[3];
+    float dir[3];
+    float cx[3];
+    float cy[3];
+    float push;
+} spt_camera;
+
+typedef struct spt_stats {
+    uint64_t samples;        /* camera paths traced (= rows*w*spp)                          */
+    uint64_t bounces;        /* closest-hit queries executed (= intersectGlobalSpheres calls) */
+    uint64_t max_depth_kills;/* paths cut by the SPT_MAX_DEPTH guard                          */
+    float    kernel_ms;      /* HIP-event time of the render kernel on its stream             */
+    float    total_ms;       /* host wall time of the call (spt_render only; incl. D2H copy)  */
+    uint32_t grid_blocks;    /* launch geometry actually used                                 */
+    uint32_t block_threads;
+} spt_stats;
+
+#define SPT_FLAG_NORMALISE 1u  /* divide by spp (cpuRender); otherwise return the raw sum (render()) */
+#define SPT_MAX_DEPTH      4096u
+#define SPT_MAX_SPHERES    4096u  /* LDS-staged: 16 B geometry per sphere */
+
+/* Creates a context on HIP device `device_id` (its own non-blocking stream, events, scratch). */
+int  spt_create(int device_id, spt_ctx** out);
+void spt_destroy(spt_ctx* ctx);
+const char* spt_last_error(const spt_ctx* ctx);  /* ctx may be NULL: last error of spt_create */
+int  spt_api_version(void);
+int  spt_device_count(void);
+
+/* Uploads the sphere table (replaces the global spheres[] + materials vector, smallpt.cpp:31-50,288-290). */
+int  spt_set_scene(spt_ctx* ctx, const spt_sphere* spheres, uint32_t n);
+
+/* Host-only helper: the camera constants of cpuRender for a w x h image (smallpt.cpp:277-279). */
+int  spt_camera_smallpt(uint32_t w, uint32_t h, spt_camera* out);
+
+/* Renders the full w x h image and copies it to out_rgb (host, w*h*3 floats).  Blocking. */
+int  spt_render(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
+                uint32_t samps_per_cell, uint64_t seed, uint32_t flags,
+                float* out_rgb, spt_stats* stats);
+
+/* Renders rows [row_begin, row_begin+row_count) of the w x h image into d_out_rgb, a DEVICE pointer
+ * to row_count*w*3 floats on this context's device.  The launch is enqueued on `hip_stream`
+ * (a hipStream_t cast to void*; NULL = the context's own stream) and returns without waiting.
+ * Pixel/sample RNG keys use the GLOBAL pixel index, so any row partition over any number of GPUs
+ * yields the same image.  Call spt_sync() before reading stats. */
+int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
+                            uint32_t row_begin, uint32_t row_count,
+                            uint32_t samps_per_cell, uint64_t seed, uint32_t flags,
+                            void* d_out_rgb, void* hip_stream);
+
+/* Waits for the last launch of this context and fills stats (may be NULL). */
+int  spt_sync(spt_ctx* ctx, spt_stats* stats);
+
+/* Tuning knobs (0 = default).  waves_per_cu caps the persistent grid; variant selects a kernel
+ * build variant for A/B runs.  Results never depend on these. */
+int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
+
+/* Image output helpers kept from the reference: toInt (smallpt.cpp:52), flipY (:125-134) and the
+ * ASCII P3 writer (:136-142).  rgb is w*h*3 floats, row 0 = bottom; the file gets the flipped image. */
+int  spt_to_int(float x);
+int  spt_write_ppm(const char* path, const float* rgb, uint32_t w, uint32_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALLPT_MI355X_H */

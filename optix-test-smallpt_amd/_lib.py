@@ -1,0 +1,67 @@
+"""ctypes binding of the C-ABI in include/smallpt_mi355x.h (libsmallpt_mi355x.so).
+
+There is deliberately no fallback: if the HIP library is missing, or no gfx950 device is present
+when a context is created, this raises.  Nothing here imports or calls the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmallpt_mi355x.so")
+
+
+class SptSphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("emission", C.c_float * 3),
+                ("color", C.c_float * 3), ("refl", C.c_int32), ("pad", C.c_uint32)]
+
+
+class SptCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("cx", C.c_float * 3),
+                ("cy", C.c_float * 3), ("push", C.c_float)]
+
+
+class SptStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("bounces", C.c_uint64), ("max_depth_kills", C.c_uint64),
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float),
+                ("grid_blocks", C.c_uint32), ("block_threads", C.c_uint32)]
+
+
+# every symbol include/smallpt_mi355x.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "spt_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "spt_destroy": (None, [_P]),
+    "spt_last_error": (C.c_char_p, [_P]),
+    "spt_api_version": (C.c_int, []),
+    "spt_device_count": (C.c_int, []),
+    "spt_set_scene": (C.c_int, [_P, _P, C.c_uint32]),
+    "spt_camera_smallpt": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(SptCamera)]),
+    "spt_render": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                             C.c_uint32, _P, C.POINTER(SptStats)]),
+    "spt_render_rows_device": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
+    "spt_sync": (C.c_int, [_P, C.POINTER(SptStats)]),
+    "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "spt_to_int": (C.c_int, [C.c_float]),
+    "spt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libsmallpt_mi355x.so and binds every symbol; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

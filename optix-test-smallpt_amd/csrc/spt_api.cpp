@@ -1,0 +1,341 @@
+// spt_api.cpp -- the C-ABI of include/smallpt_mi355x.h on top of the gfx950 megakernel.
+// Host-side only: scene upload, launch geometry, HIP-event timing, statistics, image output.
+#include "../../include/smallpt_mi355x.h"
+#include "spt_kernel.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostF3 { float x, y, z; };
+inline HostF3 hscl(HostF3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float hdot(HostF3 a, HostF3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline HostF3 hcross(HostF3 a, HostF3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline HostF3 hnormalize(HostF3 v) { float inv = 1.0f / std::sqrt(hdot(v, v)); return hscl(v, inv); }
+
+// D7 seed hashing (host side; the per-pixel / per-sample part runs in the kernel)
+inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+
+}  // namespace
+
+struct spt_ctx {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // scene
+    uint32_t n = 0;
+    float4* d_geom = nullptr;
+    float4* d_mat = nullptr;
+    uint32_t scene_cap = 0;
+    // scratch
+    float4* d_cells = nullptr;
+    size_t cells_cap = 0;          // in float4
+    float* d_out = nullptr;        // image buffer for spt_render
+    size_t out_cap = 0;            // in floats
+    uint32_t* d_queue = nullptr;   // 1 x u32 queue head + 2 x u64 counters (one 32-byte allocation)
+    unsigned long long* d_counters = nullptr;
+    // tuning
+    uint32_t blocks_per_cu = 0;
+    uint32_t variant = 0;
+    // last launch
+    bool pending = false;
+    spt_stats last{};
+    std::string error;
+
+    int fail(const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return 1;
+    }
+};
+
+#define SPT_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) return (ctx)->fail("%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" {
+
+int spt_api_version(void) { return SPT_API_VERSION; }
+
+int spt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* spt_last_error(const spt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int spt_create(int device_id, spt_ctx** out)
+{
+    if (!out) { g_create_error = "spt_create: out is NULL"; return 1; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("spt_create: no HIP device available (") + hipGetErrorString(e) +
+                         "); this library has no CPU fallback";
+        return 1;
+    }
+    if (device_id < 0 || device_id >= ndev) { g_create_error = "spt_create: device_id out of range"; return 1; }
+    spt_ctx* c = new spt_ctx;
+    c->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string("spt_create: ") + what + ": " + hipGetErrorString(err);
+        spt_destroy(c);
+        return 1;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("spt_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        spt_destroy(c);
+        return 1;
+    }
+    c->cu_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
+    void* p = nullptr;
+    if ((e = hipMalloc(&p, 32)) != hipSuccess) return bail("hipMalloc", e);
+    c->d_queue = static_cast<uint32_t*>(p);
+    c->d_counters = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + 16);
+    *out = c;
+    return 0;
+}
+
+void spt_destroy(spt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_geom) (void)hipFree(c->d_geom);
+    if (c->d_mat) (void)hipFree(c->d_mat);
+    if (c->d_cells) (void)hipFree(c->d_cells);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
+{
+    if (!c) return 1;
+    c->blocks_per_cu = blocks_per_cu;
+    c->variant = variant;
+    return 0;
+}
+
+// Builds the device tables from the reference-shaped sphere records.  All derived values are single
+// IEEE operations on the host, bit-identical to evaluating them per bounce:
+//   r*r (scene.cpp:133), pmax = fmaxf(color) (smallpt.cpp:177), color*(1/pmax) (smallpt.cpp:192).
+int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
+{
+    if (!c) return 1;
+    if (n > SPT_MAX_SPHERES) return c->fail("spt_set_scene: %u spheres > SPT_MAX_SPHERES (%u)", n, SPT_MAX_SPHERES);
+    if (n && !s) return c->fail("spt_set_scene: spheres is NULL");
+    for (uint32_t i = 0; i < n; ++i)
+        if (s[i].refl < SPT_DIFF || s[i].refl > SPT_REFR) return c->fail("spt_set_scene: sphere %u has refl=%d", i, s[i].refl);
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    const uint32_t cap = n ? n : 1;
+    if (cap > c->scene_cap) {
+        if (c->d_geom) (void)hipFree(c->d_geom);
+        if (c->d_mat) (void)hipFree(c->d_mat);
+        c->d_geom = c->d_mat = nullptr;
+        c->scene_cap = 0;
+        SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_geom), sizeof(float4) * cap));
+        SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_mat), sizeof(float4) * 3 * cap));
+        c->scene_cap = cap;
+    }
+    std::vector<float4> geom(cap), mat(3 * (size_t)cap);
+    for (uint32_t i = 0; i < n; ++i) {
+        const spt_sphere& sp = s[i];
+        geom[i] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius * sp.radius);
+        const float pmax = std::fmax(std::fmax(sp.color[0], sp.color[1]), sp.color[2]);
+        const float inv = 1.0f / pmax;
+        float reflbits;
+        std::memcpy(&reflbits, &sp.refl, 4);
+        mat[3 * i + 0] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], reflbits);
+        mat[3 * i + 1] = make_float4(sp.color[0], sp.color[1], sp.color[2], pmax);
+        mat[3 * i + 2] = make_float4(sp.color[0] * inv, sp.color[1] * inv, sp.color[2] * inv, 0.0f);
+    }
+    SPT_HIP(c, hipMemcpy(c->d_geom, geom.data(), sizeof(float4) * cap, hipMemcpyHostToDevice));
+    SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
+    c->n = n;
+    return 0;
+}
+
+// smallpt.cpp:277-279 (D10: cx = (w*.5135/h, 0, 0))
+int spt_camera_smallpt(uint32_t w, uint32_t h, spt_camera* out)
+{
+    if (!out || w == 0 || h == 0) return 1;
+    const HostF3 o{50, 52, 295.6f};
+    const HostF3 dir = hnormalize(HostF3{0, (float)-0.042612, -1});
+    const HostF3 cx{(float)((int)w * .5135 / (int)h), 0, 0};
+    const HostF3 cy = hscl(hnormalize(hcross(cx, dir)), (float).5135);
+    out->origin[0] = o.x; out->origin[1] = o.y; out->origin[2] = o.z;
+    out->dir[0] = dir.x; out->dir[1] = dir.y; out->dir[2] = dir.z;
+    out->cx[0] = cx.x; out->cx[1] = cx.y; out->cx[2] = cx.z;
+    out->cy[0] = cy.x; out->cy[1] = cy.y; out->cy[2] = cy.z;
+    out->push = 140.0f;
+    return 0;
+}
+
+int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h,
+                           uint32_t row_begin, uint32_t row_count, uint32_t samps, uint64_t seed,
+                           uint32_t flags, void* d_out_rgb, void* hip_stream)
+{
+    if (!c) return 1;
+    if (!cam || !d_out_rgb) return c->fail("spt_render_rows_device: NULL argument");
+    if (w == 0 || h == 0 || samps == 0) return c->fail("spt_render_rows_device: empty image or samps == 0");
+    if ((uint64_t)w * h > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: w*h exceeds 2^32-1 pixels");
+    if (row_count == 0 || (uint64_t)row_begin + row_count > h) return c->fail("spt_render_rows_device: row band [%u,+%u) outside image height %u", row_begin, row_count, h);
+    if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: spp overflows 32 bits");
+    const uint64_t npix = (uint64_t)row_count * w;
+    if (npix * 4 > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: band has more than 2^30 pixels; split it");
+    if (!c->d_geom) return c->fail("spt_render_rows_device: no scene set (call spt_set_scene)");
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) { SPT_HIP(c, hipEventSynchronize(c->ev_stop)); }
+
+    const size_t ntasks = (size_t)npix * 4;
+    if (ntasks > c->cells_cap) {
+        if (c->d_cells) (void)hipFree(c->d_cells);
+        c->d_cells = nullptr; c->cells_cap = 0;
+        SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_cells), ntasks * sizeof(float4)));
+        c->cells_cap = ntasks;
+    }
+
+    spt::KParams P{};
+    std::memcpy(P.cam_o, cam->origin, 12); std::memcpy(P.cam_d, cam->dir, 12);
+    std::memcpy(P.cam_cx, cam->cx, 12); std::memcpy(P.cam_cy, cam->cy, 12);
+    P.cam_push = cam->push;
+    P.w = w; P.h = h; P.row_begin = row_begin; P.row_count = row_count;
+    P.samps = samps; P.ntasks = (uint32_t)ntasks;
+    P.s0 = mix32((uint32_t)seed + 0x243F6A88u);
+    P.s1 = mix32((uint32_t)(seed >> 32) ^ P.s0 ^ 0x85A308D3u);
+    P.n = c->n; P.n_pad = c->n ? c->n : 1;
+    P.geom = c->d_geom; P.mat = c->d_mat;
+    P.cells = c->d_cells; P.queue = c->d_queue; P.counters = c->d_counters;
+
+    // launch geometry: a persistent grid that fills the chip; the task queue makes any size correct
+    const int mat_lds = (c->n <= 256) ? 1 : 0;
+    const size_t lds = spt_k_lds_bytes(P.n_pad, mat_lds);
+    const int threads = spt_k_block_threads();
+    uint32_t per_cu = c->blocks_per_cu;
+    if (per_cu == 0) {
+        const uint32_t by_lds = (uint32_t)((160u * 1024u) / lds);
+        per_cu = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
+    }
+    uint64_t blocks = (uint64_t)c->cu_count * per_cu;
+    const uint64_t needed = (ntasks + threads - 1) / threads;
+    if (blocks > needed) blocks = needed;
+    if (blocks < 1) blocks = 1;
+
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 32, st));
+    SPT_HIP(c, hipEventRecord(c->ev_start, st));
+    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, st));
+    const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
+    SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
+    SPT_HIP(c, hipEventRecord(c->ev_stop, st));
+    c->pending = true;
+    c->last = spt_stats{};
+    c->last.samples = npix * 4ull * samps;
+    c->last.grid_blocks = (uint32_t)blocks;
+    c->last.block_threads = (uint32_t)threads;
+    return 0;
+}
+
+int spt_sync(spt_ctx* c, spt_stats* stats)
+{
+    if (!c) return 1;
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) {
+        SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+        float ms = 0.f;
+        SPT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        unsigned long long ctr[2] = {0, 0};
+        SPT_HIP(c, hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
+        c->last.kernel_ms = ms;
+        c->last.bounces = ctr[0];
+        c->last.max_depth_kills = ctr[1];
+        c->pending = false;
+    }
+    if (stats) *stats = c->last;
+    return 0;
+}
+
+int spt_render(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t samps, uint64_t seed,
+               uint32_t flags, float* out_rgb, spt_stats* stats)
+{
+    if (!c) return 1;
+    if (!out_rgb) return c->fail("spt_render: out_rgb is NULL");
+    const auto t0 = std::chrono::steady_clock::now();
+    SPT_HIP(c, hipSetDevice(c->device));
+    const size_t nfl = (size_t)w * h * 3;
+    if (nfl == 0) return c->fail("spt_render: empty image");
+    if (nfl > c->out_cap) {
+        if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_out = nullptr; c->out_cap = 0;
+        SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), nfl * sizeof(float)));
+        c->out_cap = nfl;
+    }
+    if (int rc = spt_render_rows_device(c, cam, w, h, 0, h, samps, seed, flags, c->d_out, nullptr)) return rc;
+    SPT_HIP(c, hipMemcpyAsync(out_rgb, c->d_out, nfl * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    SPT_HIP(c, hipStreamSynchronize(c->stream));
+    if (int rc = spt_sync(c, nullptr)) return rc;
+    c->last.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = c->last;
+    return 0;
+}
+
+// smallpt.cpp:52
+int spt_to_int(float x)
+{
+    const float cl = x < 0.f ? 0.f : (x > 1.f ? 1.f : x);
+    return (int)(std::pow((double)cl, 1 / 2.2) * 255 + .5);
+}
+
+// flipY (smallpt.cpp:125-134) + writeImage (smallpt.cpp:136-142); unlike the reference the file is closed.
+int spt_write_ppm(const char* path, const float* rgb, uint32_t w, uint32_t h)
+{
+    if (!path || !rgb || !w || !h) return 1;
+    FILE* f = std::fopen(path, "w");
+    if (!f) return 1;
+    std::fprintf(f, "P3\n%u %u\n%d\n", w, h, 255);
+    for (uint32_t r = 0; r < h; ++r) {
+        const float* row = rgb + (size_t)(h - 1 - r) * w * 3;
+        for (uint32_t x = 0; x < w; ++x)
+            std::fprintf(f, "%d %d %d ", spt_to_int(row[3 * x]), spt_to_int(row[3 * x + 1]), spt_to_int(row[3 * x + 2]));
+    }
+    return std::fclose(f) == 0 ? 0 : 1;
+}
+
+}  // extern "C"

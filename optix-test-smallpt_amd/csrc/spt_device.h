@@ -1,0 +1,81 @@
+// spt_device.h -- device-side arithmetic of the MI355X path-tracing megakernel (gfx950 only).
+//
+// Arithmetic contract (DESIGN.md "Arithmetic spec"): every float operation below is a single IEEE
+// binary32 operation; the translation unit is compiled with -ffp-contract=off so that hipcc never
+// fuses a*b+c (the reference is host C++ on x86-64: separate mul/add), and with
+// -fhip-fp32-correctly-rounded-divide-sqrt so '/' and sqrtf are the correctly rounded operations.
+// Reference lines are cited as file:line relative to the reference tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spt {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+// optix dot(): x*x' + y*y' + z*z', left to right
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b)
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// optix normalize(): v * (1.0f / sqrtf(dot(v, v)))
+__device__ __forceinline__ f3 normalize(f3 v)
+{
+    float inv = 1.0f / __builtin_sqrtf(dot(v, v));
+    return v * inv;
+}
+
+// ---- D7: counter-based RNG (replaces mt19937 + uniform_real_distribution, smallpt.cpp:157,319) ----
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+constexpr uint32_t kGolden = 0x9E3779B9u;
+// ctr = [31:29] branch | [28] camera | [27:2] depth | [1:0] dimension
+__device__ __forceinline__ float rng_uniform(uint32_t k0, uint32_t k1, uint32_t ctr)
+{
+    uint32_t x = k0 + ctr * kGolden;
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x += k1;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return (float)(x >> 8) * 0x1p-24f;
+}
+
+// ---- D17: sin/cos of 2*pi*u, quadrant reduction + odd degree-9 polynomial, no FMA ----
+__device__ __forceinline__ float sin_quarter(float z)
+{
+    const float c1 = 0x1.921fb4p+0f, c3 = -0x1.4abbb6p-1f, c5 = 0x1.46676ep-4f,
+                c7 = -0x1.3232fap-8f, c9 = 0x1.3c4b2cp-13f;
+    float z2 = z * z;
+    float p = c9;
+    p = p * z2 + c7;
+    p = p * z2 + c5;
+    p = p * z2 + c3;
+    p = p * z2 + c1;
+    return p * z;
+}
+__device__ __forceinline__ void sincos2pi(float u, float& s, float& c)
+{
+    float t = 4.0f * u;
+    int q = (int)t;
+    float f = t - (float)q;
+    float S = sin_quarter(f);
+    float C = sin_quarter(1.0f - f);
+    float s0 = (q & 1) ? C : S;
+    float c0 = (q & 1) ? S : C;
+    s = (q & 2) ? -s0 : s0;            // q: 0 S, 1 C, 2 -S, 3 -C
+    c = ((q + 1) & 2) ? -c0 : c0;      // q: 0 C, 1 -S, 2 -C, 3 S
+}
+
+}  // namespace spt

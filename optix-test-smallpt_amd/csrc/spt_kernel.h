@@ -1,0 +1,35 @@
+// spt_kernel.h -- launch parameters shared by the kernel TU (hipcc) and the C-ABI TU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPT_K_MAX_DEPTH 4096u
+
+namespace spt {
+
+struct KParams {
+    // camera (smallpt.cpp:277-279,333)
+    float cam_o[3], cam_d[3], cam_cx[3], cam_cy[3];
+    float cam_push;
+    // image / band
+    uint32_t w, h, row_begin, row_count;
+    uint32_t samps;          // samples per jitter cell (spp = 4*samps)
+    uint32_t ntasks;         // 4 * row_count * w
+    // RNG seed hashes (D7), computed on the host once per render
+    uint32_t s0, s1;
+    // scene tables (device memory)
+    uint32_t n, n_pad;
+    const float4* geom;      // n x {cx, cy, cz, r*r}
+    const float4* mat;       // n x 3: {e.xyz, refl bits}, {color.xyz, pmax}, {color*(1/pmax), 0}
+    // outputs
+    float4* cells;           // ntasks cell sums
+    uint32_t* queue;         // task queue head (zeroed before launch)
+    unsigned long long* counters;  // [0] bounces, [1] depth-cap kills
+};
+
+}  // namespace spt
+
+extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds);
+extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, hipStream_t stream);
+extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream);
+extern "C" int spt_k_block_threads(void);

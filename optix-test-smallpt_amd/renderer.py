@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference's render interface on top of the C-ABI.
+
+``Renderer.render`` plays the role of ``Renderer::render`` (smallpt.cpp:692-814, un-normalised sum,
+row 0 = bottom) and ``Renderer.cpu_render_equivalent`` that of ``cpuRender`` (smallpt.cpp:269-379,
+normalised).  PyTorch is only used for device memory / streams when the caller wants the image to
+stay resident in HBM.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import SptCamera, SptStats, load_library
+from .scene import SPHERE_DTYPE
+
+FLAG_NORMALISE = 1
+
+
+class SptError(RuntimeError):
+    pass
+
+
+def smallpt_camera(w, h):
+    """Camera constants of cpuRender (smallpt.cpp:277-279) for a w x h image."""
+    lib = load_library()
+    cam = SptCamera()
+    if lib.spt_camera_smallpt(w, h, C.byref(cam)):
+        raise SptError("spt_camera_smallpt failed")
+    return cam
+
+
+def _stats_dict(st):
+    return {"samples": int(st.samples), "bounces": int(st.bounces), "max_depth_kills": int(st.max_depth_kills),
+            "kernel_ms": float(st.kernel_ms), "total_ms": float(st.total_ms),
+            "grid_blocks": int(st.grid_blocks), "block_threads": int(st.block_threads)}
+
+
+class Renderer:
+    """One context = one HIP device (spt_create)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        if self._lib.spt_create(int(device_id), C.byref(h)):
+            raise SptError(self._lib.spt_last_error(None).decode())
+        self._h = h
+        self.device_id = int(device_id)
+        self._scene = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.spt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise SptError(self._lib.spt_last_error(self._h).decode())
+
+    def set_scene(self, spheres):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        self._scene = spheres
+        self._check(self._lib.spt_set_scene(self._h, spheres.ctypes.data_as(C.c_void_p), len(spheres)))
+
+    def set_tuning(self, blocks_per_cu=0, variant=0):
+        self._check(self._lib.spt_set_tuning(self._h, blocks_per_cu, variant))
+
+    def render(self, w, h, samps_per_cell, seed=0, normalise=False, camera=None):
+        """Full image to host memory: (h, w, 3) float32, row 0 = bottom.  Returns (image, stats)."""
+        cam = camera if camera is not None else smallpt_camera(w, h)
+        out = np.empty((h, w, 3), dtype=np.float32)
+        st = SptStats()
+        self._check(self._lib.spt_render(self._h, C.byref(cam), w, h, samps_per_cell, seed,
+                                         FLAG_NORMALISE if normalise else 0,
+                                         out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, _stats_dict(st)
+
+    def cpu_render_equivalent(self, w, h, spp, seed=0):
+        """cpuRender(argv[1]=spp) semantics: samps = spp/4 (smallpt.cpp:276), normalised image."""
+        return self.render(w, h, max(1, int(spp) // 4), seed=seed, normalise=True)
+
+    def render_rows_device(self, out_tensor, w, h, row_begin, row_count, samps_per_cell, seed=0,
+                           normalise=False, camera=None, stream=None):
+        """Enqueues the render of rows [row_begin, row_begin+row_count) into ``out_tensor`` (a CUDA/HIP
+        float32 torch tensor with row_count*w*3 elements on this context's device).  Asynchronous:
+        call ``sync()`` for completion + statistics.  ``stream``: a raw hipStream_t handle (int), e.g.
+        ``torch.cuda.current_stream().cuda_stream``; None = the context's own stream."""
+        if out_tensor.numel() != row_count * w * 3 or not out_tensor.is_contiguous():
+            raise ValueError("out_tensor must be contiguous with row_count*w*3 float32 elements")
+        if str(out_tensor.dtype) != "torch.float32" or out_tensor.device.type != "cuda":
+            raise ValueError("out_tensor must be a float32 tensor on the GPU")
+        cam = camera if camera is not None else smallpt_camera(w, h)
+        self._check(self._lib.spt_render_rows_device(
+            self._h, C.byref(cam), w, h, row_begin, row_count, samps_per_cell, seed,
+            FLAG_NORMALISE if normalise else 0, C.c_void_p(out_tensor.data_ptr()),
+            C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        st = SptStats()
+        self._check(self._lib.spt_sync(self._h, C.byref(st)))
+        return _stats_dict(st)
+
+
+def to_int(x):
+    """toInt, smallpt.cpp:52."""
+    return load_library().spt_to_int(float(x))
+
+
+def write_ppm(path, rgb):
+    """flipY + writeImage (smallpt.cpp:125-142) for an (h, w, 3) float32 image, row 0 = bottom."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    if load_library().spt_write_ppm(str(path).encode(), rgb.ctypes.data_as(C.c_void_p), w, h):
+        raise SptError(f"cannot write {path}")

@@ -1,0 +1,445 @@
+/*
+ * smallpt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See smallpt_oracle.h
+ * for the role and the parity-pin status ("parity unpinned by the reference's own tests";
+ * pinned to the SURVEY.md 8(c) known-answer values).
+ *
+ * Plain C restatement of the reference algorithm.  Every function cites the reference lines it
+ * follows (paths relative to /root/reference).  Arithmetic rules (DESIGN.md "Arithmetic spec"):
+ *   - every float operation is one IEEE-754 binary32 operation, round-to-nearest-even, NO
+ *     contraction into FMA (the reference is host C++ compiled for x86-64: mul and add are
+ *     separate SSE instructions).  Built with -ffp-contract=off, never -ffast-math.
+ *   - where the reference's C++ promotes to double (double literals / size_t operands,
+ *     smallpt.cpp:210,256,331-332) this file does the same in double.
+ *   - sqrtf and '/' are the correctly rounded IEEE operations.
+ *   - no libm transcendental is on the path: sin/cos come from orc_sincos2pi (D17), the RNG is
+ *     the counter-based generator of D7.
+ */
+#include "smallpt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { float x, y, z; } f3;
+
+#define ORC_INF 1e20f /* maths.h:16 */
+
+static inline f3 mk(float x, float y, float z) { f3 r = { x, y, z }; return r; }
+static inline f3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
+static inline void st(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+/* optixu_math semantics (SURVEY.md 8(c) "Semantics assumed"): componentwise ops,
+ * dot = x*x' + y*y' + z*z' left to right, normalize = v * (1/sqrt(dot(v,v))). */
+static inline f3 add(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 scl(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+static inline float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline f3 cross(f3 a, f3 b)
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline f3 normalize(f3 v)
+{
+    float invLen = 1.0f / sqrtf(dot(v, v));
+    return scl(v, invLen);
+}
+
+/* ---------------------------------------------------------------- D7: counter-based RNG ----
+ * Replaces std::mt19937 + uniform_real_distribution<float> (smallpt.cpp:157,292,319).  The
+ * mt19937 stream is consumed in wavefront order across a whole image row, which cannot be
+ * reproduced by independent lanes; D7 keys a bijective 32-bit mixer by (seed, pixel, sample)
+ * and addresses it by (branch, depth, dimension), so the value of every random decision is
+ * independent of scheduling, of the GPU count and of how many numbers other paths drew. */
+uint32_t orc_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+
+void orc_sample_keys(uint64_t seed, uint32_t pixel_idx, uint32_t sample_idx, uint32_t* k0, uint32_t* k1)
+{
+    uint32_t s0 = orc_mix32((uint32_t)seed + 0x243F6A88u);
+    uint32_t s1 = orc_mix32((uint32_t)(seed >> 32) ^ s0 ^ 0x85A308D3u);
+    uint32_t p0 = orc_mix32(pixel_idx + s0);
+    uint32_t p1 = orc_mix32(pixel_idx ^ s1);
+    *k0 = orc_mix32(p0 ^ (sample_idx * 0x9E3779B9u));
+    *k1 = orc_mix32(p1 + sample_idx * 0x85EBCA6Bu);
+}
+
+uint32_t orc_rng_bits(uint32_t k0, uint32_t k1, uint32_t ctr)
+{
+    uint32_t x = k0 + ctr * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x += k1;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+
+float orc_rng_uniform(uint32_t k0, uint32_t k1, uint32_t ctr)
+{
+    /* 24 random bits -> [0,1) exactly representable; never 1.0 */
+    return (float)(orc_rng_bits(k0, k1, ctr) >> 8) * 0x1p-24f;
+}
+
+/* counter layout: [31:29] branch bits (bit 29+k set = transmitted child of the split at depth k),
+ * [28] camera flag, [27:2] depth, [1:0] dimension j. */
+#define CTR_CAM(j) ((1u << 28) | (uint32_t)(j))
+static inline uint32_t ctr_of(uint32_t branch, uint32_t depth, uint32_t j)
+{
+    return (branch << 29) | (depth << 2) | j;
+}
+enum { J_RR = 0, J_R1 = 1, J_R2 = 2 };
+
+/* --------------------------------------------------------------- D17: sin/cos(2*pi*u) ------
+ * The reference calls libm cos()/sin() on r1 = 2*M_PI*u (smallpt.cpp:210,212); libm results are
+ * not bit-reproducible across C libraries or on a GPU, so the spec fixes one polynomial:
+ * quadrant q = floor(4u), f = 4u - q (both exact), S(z) = sin(pi/2 z) ~ odd degree-9 polynomial
+ * in Horner form (|err| <= 2.1e-7 in binary32), cos(pi/2 f) = S(1 - f). */
+static inline float sin_quarter(float z)
+{
+    const float c1 = 0x1.921fb4p+0f, c3 = -0x1.4abbb6p-1f, c5 = 0x1.46676ep-4f,
+                c7 = -0x1.3232fap-8f, c9 = 0x1.3c4b2cp-13f;
+    float z2 = z * z;
+    float p = c9;
+    p = p * z2 + c7;
+    p = p * z2 + c5;
+    p = p * z2 + c3;
+    p = p * z2 + c1;
+    return p * z;
+}
+
+void orc_sincos2pi(float u, float* s, float* c)
+{
+    float t = 4.0f * u;          /* exact */
+    int q = (int)t;              /* 0..3 for u in [0,1) */
+    float f = t - (float)q;      /* exact */
+    float S = sin_quarter(f);
+    float C = sin_quarter(1.0f - f);
+    switch (q & 3) {
+    case 0: *s = S;  *c = C;  break;
+    case 1: *s = C;  *c = -S; break;
+    case 2: *s = -S; *c = -C; break;
+    default: *s = -C; *c = S; break;
+    }
+}
+
+/* ---------------------------------------------------------------- geometry ---------------- */
+/* scene.cpp:129-140 Sphere::intersectAnalytic (D1).  eps = 1e-4 stored in a float (:133). */
+static inline float intersect_analytic(f3 center, float radius, f3 o, f3 d, f3* x)
+{
+    f3 op = sub(center, o);                                   /* :132 */
+    float t, eps = 1e-4f, b = dot(op, d);                     /* :133 */
+    float det = b * b - dot(op, op) + radius * radius;        /* :133 */
+    if (det < 0) return ORC_INF; else det = sqrtf(det);       /* :134 */
+    float dist = (t = b - det) > eps ? t : ((t = b + det) > eps ? t : 0); /* :135 */
+    if (dist > 0) {                                           /* :136 */
+        *x = add(o, scl(d, dist));                            /* :137 */
+        return dist;
+    }
+    return ORC_INF;                                           /* :139, SphereHit{} dist = inf */
+}
+
+float orc_intersect_analytic(const orc_sphere* s, const float o[3], const float d[3], float x[3])
+{
+    f3 hx = mk(0, 0, 0);
+    float t = intersect_analytic(ld(s->center), s->radius, ld(o), ld(d), &hx);
+    st(x, hx);
+    return t;
+}
+
+/* scene.cpp:118-127 Sphere::makeHit(SphereHit) */
+void orc_make_hit_normal(const orc_sphere* s, const float x[3], float n[3])
+{
+    st(n, normalize(sub(ld(x), ld(s->center))));              /* :124 */
+}
+
+/* smallpt.cpp:54-70 intersectGlobalSpheres (D16: ascending index, strict '<', dist > 0). */
+static inline int intersect_global_spheres(const orc_sphere* sph, uint32_t n, f3 o, f3 d,
+                                           float* dist, f3* x, f3* nrm)
+{
+    float nearest = ORC_INF;                                  /* :57, SphereHit{} */
+    f3 nx = mk(0, 0, 0);
+    int inst = -1;
+    for (uint32_t i = 0; i < n; ++i) {                        /* :59 */
+        f3 cx = mk(0, 0, 0);
+        float cur = intersect_analytic(ld(sph[i].center), sph[i].radius, o, d, &cx); /* :60 */
+        if (cur > 0.f && cur < nearest) {                     /* :61 */
+            nearest = cur; nx = cx; inst = (int)i;            /* :62-63 */
+        }
+    }
+    if (nearest == ORC_INF) return -1;                        /* :66-67 */
+    *dist = nearest;
+    *x = nx;
+    *nrm = normalize(sub(nx, ld(sph[inst].center)));          /* :69 -> scene.cpp:124 */
+    return inst;
+}
+
+int orc_intersect_global_spheres(const orc_sphere* s, uint32_t n, const float o[3], const float d[3],
+                                 float* dist, float x[3], float nrm[3])
+{
+    f3 hx = mk(0, 0, 0), hn = mk(0, 0, 0);
+    float t = ORC_INF;
+    int id = intersect_global_spheres(s, n, ld(o), ld(d), &t, &hx, &hn);
+    *dist = t; st(x, hx); st(nrm, hn);
+    return id;
+}
+
+/* scene.cpp:52-70 triIntersect.  The reference uses double literals 1.0/0.0 here: d is computed
+ * as (float)(1.0 / (double)dot). Fixture only. */
+void orc_tri_intersect(const float ro_[3], const float rd_[3], const float v0_[3], const float v1_[3],
+                       const float v2_[3], float* t_, float* u_, float* v_)
+{
+    f3 ro = ld(ro_), rd = ld(rd_), v0 = ld(v0_), v1 = ld(v1_), v2 = ld(v2_);
+    f3 v1v0 = sub(v1, v0), v2v0 = sub(v2, v0), rov0 = sub(ro, v0);
+    f3 n = cross(v1v0, v2v0);
+    f3 q = cross(rov0, rd);
+    float d = (float)(1.0 / (double)dot(rd, n));
+    float u = d * dot(scl(q, -1.0f), v2v0);
+    float v = d * dot(q, v1v0);
+    float t = d * dot(scl(n, -1.0f), rov0);
+    if (u < 0.0 || u > 1.0 || v < 0.0 || (u + v) > 1.0) t = ORC_INF;
+    *t_ = t; *u_ = u; *v_ = v;
+}
+
+/* ---------------------------------------------------------------- camera ------------------ */
+/* smallpt.cpp:277-279 with D10 (cx = (w*.5135/h, 0, 0)). */
+void orc_camera_smallpt(uint32_t w, uint32_t h, orc_camera* cam)
+{
+    f3 o = mk(50, 52, 295.6f);
+    f3 dir = normalize(mk(0, (float)-0.042612, -1));          /* :277 */
+    f3 cx = mk((float)((int)w * .5135 / (int)h), 0, 0);       /* :278, double then float */
+    f3 cy = scl(normalize(cross(cx, dir)), (float).5135);     /* :279 */
+    st(cam->origin, o); st(cam->dir, dir); st(cam->cx, cx); st(cam->cy, cy);
+    cam->push = 140.0f;                                       /* :333 */
+}
+
+/* smallpt.cpp:327-333 (D8 tent filter, D10 camera).  jitterSize = 2 (:285). */
+static inline void camera_ray(const orc_camera* cam, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
+                              uint32_t sx, uint32_t sy, float u1, float u2, f3* o, f3* d)
+{
+    const float r1 = 2 * u1;                                              /* :327 */
+    const float dx = r1 < 1 ? sqrtf(r1) - 1 : 1 - sqrtf(2 - r1);          /* :328 */
+    const float r2 = 2 * u2;                                              /* :329 */
+    const float dy = r2 < 1 ? sqrtf(r2) - 1 : 1 - sqrtf(2 - r2);          /* :330 */
+    /* :331-332: size_t + double literal => the bracket is evaluated in double, then converted to
+     * float by operator*(float3, float). */
+    const double ax = (((double)sx + .5 + (double)dx) / 2.0 + (double)px) / (double)(int)w - .5;
+    const double ay = (((double)sy + .5 + (double)dy) / 2.0 + (double)py) / (double)(int)h - .5;
+    const f3 dd = add(add(scl(ld(cam->cx), (float)ax), scl(ld(cam->cy), (float)ay)), ld(cam->dir));
+    *o = add(ld(cam->origin), scl(dd, cam->push));                         /* :333 */
+    *d = normalize(dd);
+}
+
+void orc_camera_ray(const orc_camera* cam, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
+                    uint32_t sx, uint32_t sy, float u1, float u2, float o[3], float d[3])
+{
+    f3 ro, rd;
+    camera_ray(cam, w, h, px, py, sx, sy, u1, u2, &ro, &rd);
+    st(o, ro); st(d, rd);
+}
+
+/* smallpt.cpp:52 */
+int orc_to_int(float x)
+{
+    float c = x < 0.f ? 0.f : (x > 1.f ? 1.f : x);
+    return (int)(pow((double)c, 1 / 2.2) * 255 + .5);
+}
+
+/* ---------------------------------------------------------------- one sample -------------- */
+typedef struct {
+    f3 o, d, w;          /* PathContrib::currentRay, ::weight (smallpt.cpp:106-111) */
+    uint32_t depth;      /* PathContrib::depth */
+    uint32_t branch;     /* D7 counter bits */
+} path_t;
+
+typedef struct {
+    const orc_sphere* sph;
+    uint32_t n;
+    int zero_cut;
+    uint64_t bounces;
+    uint64_t depth_kills;
+} trace_ctx;
+
+/* extend() smallpt.cpp:120-123 + D18 depth cap + zero-weight cut (SURVEY.md section 7,
+ * "Zero-throughput waste": a path whose weight is exactly 0 can never contribute again). */
+static inline int make_child(trace_ctx* tc, const path_t* p, f3 o, f3 d, f3 factor, uint32_t branch, path_t* c)
+{
+    c->o = o; c->d = d;
+    c->w = mul(p->w, factor);                                  /* :122 */
+    c->depth = p->depth + 1;
+    c->branch = branch;
+    if (c->depth >= ORC_MAX_DEPTH) { tc->depth_kills++; return 0; }
+    if (tc->zero_cut && c->w.x == 0.f && c->w.y == 0.f && c->w.z == 0.f) return 0;
+    return 1;
+}
+
+/* Traces the whole path tree of one camera ray; emission events are added to *acc in DFS
+ * pre-order, reflected child before transmitted child (smallpt.cpp:251-252 order). */
+static void trace_sample(trace_ctx* tc, path_t cam_path, uint32_t k0, uint32_t k1, f3* acc)
+{
+    path_t stack[4];
+    int sp = 0;
+    stack[sp++] = cam_path;
+    while (sp > 0) {
+        path_t p = stack[--sp];
+        for (;;) {
+            /* ---- intersectGlobalSpheres, smallpt.cpp:352 -> :144-152 -> :54-70 ---- */
+            float dist; f3 hx, n;
+            tc->bounces++;
+            int id = intersect_global_spheres(tc->sph, tc->n, p.o, p.d, &dist, &hx, &n);
+            if (id < 0) break;                                 /* :168 miss => black (D13) */
+            /* ---- shadePaths body, smallpt.cpp:170-263 ---- */
+            const orc_sphere* m = &tc->sph[id];                /* :170 */
+            f3 nl = dot(n, p.d) < 0 ? n : scl(n, -1.0f);       /* :174 with the flip (D2) */
+            f3 f = ld(m->color);                               /* :175 */
+            const float pmax = fmaxf(fmaxf(f.x, f.y), f.z);    /* :177 optix::fmaxf(float3) */
+            *acc = add(*acc, mul(p.w, ld(m->emission)));       /* :179 (D4) */
+            const uint32_t depth = p.depth;                    /* :185 */
+            if (depth > 5) {                                   /* :188 (D5) */
+                if (orc_rng_uniform(k0, k1, ctr_of(p.branch, depth, J_RR)) < pmax)
+                    f = scl(f, 1 / pmax);                      /* :192 */
+                else
+                    break;                                     /* :196 */
+            }
+            /* D3: the new origin is offset 0.02 along the side the outgoing ray leaves on */
+            f3 off = scl(nl, 0.02f);                           /* :172 */
+            f3 x_out = add(hx, off);
+            path_t c;
+            if (m->refl == ORC_DIFF) {                         /* :208 */
+                float u1 = orc_rng_uniform(k0, k1, ctr_of(p.branch, depth, J_R1));
+                float r2 = orc_rng_uniform(k0, k1, ctr_of(p.branch, depth, J_R2));
+                float r2s = sqrtf(r2);                         /* :210 */
+                float sn, cs;
+                orc_sincos2pi(u1, &sn, &cs);                   /* :210,212 via D17 */
+                f3 w = nl;                                     /* :211 */
+                f3 u = normalize(cross(((double)fabsf(w.x) > .1 ? mk(0, 1, 0) : mk(1, 0, 0)), w));
+                f3 v = cross(w, u);
+                f3 d = normalize(add(add(scl(scl(u, cs), r2s), scl(scl(v, sn), r2s)),
+                                     scl(w, sqrtf(1 - r2))));  /* :212 */
+                if (!make_child(tc, &p, x_out, d, f, p.branch, &c)) break; /* :214 */
+                p = c;
+                continue;
+            }
+            /* :218 reflRay(x, r.d - n*2*dot(n, r.d)) */
+            f3 rd = sub(p.d, scl(scl(n, 2.0f), dot(n, p.d)));
+            if (m->refl == ORC_SPEC) {                         /* :219 */
+                if (!make_child(tc, &p, x_out, rd, f, p.branch, &c)) break; /* :221 */
+                p = c;
+                continue;
+            }
+            const int into = dot(n, nl) > 0;                   /* :225 */
+            const float nc = 1;                                /* :226 */
+            const float nt = 1.5;                              /* :227 */
+            const float nnt = into ? nc / nt : nt / nc;        /* :228 */
+            const float ddn = dot(p.d, nl);                    /* :229 */
+            const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn); /* :230 */
+            if (cos2t < 0) {                                   /* :232 total internal reflection */
+                if (!make_child(tc, &p, x_out, rd, f, p.branch, &c)) break; /* :234 */
+                p = c;
+                continue;
+            }
+            /* :238 */
+            f3 tdir = normalize(sub(scl(p.d, nnt), scl(n, (float)(into ? 1 : -1) * (ddn * nnt + sqrtf(cos2t)))));
+            const float a = nt - nc;                           /* :240 */
+            const float b = nt + nc;                           /* :241 */
+            const float R0 = a * a / (b * b);                  /* :242 */
+            const float cc = 1 - (into ? -ddn : dot(tdir, n)); /* :243 */
+            const float c2 = cc * cc;                          /* :244 */
+            const float Re = R0 + (1 - R0) * c2 * c2 * cc;     /* :245 */
+            const float Tr = 1 - Re;                           /* :246 */
+            f3 x_in = sub(hx, off);                            /* D3: transmitted ray leaves on the -nl side */
+            if (depth <= 2) {                                  /* :248 split (D6) */
+                path_t ct;
+                int has_t = make_child(tc, &p, x_in, tdir, scl(f, Tr), p.branch | (1u << depth), &ct); /* :252 */
+                int has_r = make_child(tc, &p, x_out, rd, scl(f, Re), p.branch, &c);                    /* :251 */
+                if (has_t) stack[sp++] = ct;                   /* processed after the reflected subtree */
+                if (!has_r) break;
+                p = c;
+                continue;
+            }
+            const float P = (float)(.25 + .5 * Re);            /* :256 (double literals) */
+            if (orc_rng_uniform(k0, k1, ctr_of(p.branch, depth, J_R1)) < P) { /* :257 */
+                /* :259 f * Re / P ; optix operator/(float3,float) multiplies by 1.0f/P */
+                if (!make_child(tc, &p, x_out, rd, scl(scl(f, Re), 1.0f / P), p.branch, &c)) break;
+                p = c;
+                continue;
+            }
+            /* :263 f * Tr / (1.f - P) */
+            if (!make_child(tc, &p, x_in, tdir, scl(scl(f, Tr), 1.0f / (1.f - P)), p.branch, &c)) break;
+            p = c;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- render ------------------ */
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* cpuRender smallpt.cpp:269-361: per row (:317), per pixel/cell/sample in the order of
+ * foreachSampleInRow (:294-314).  D9 accumulation order: every emission event is added straight
+ * into its cell accumulator in (sample-major, DFS) order; the pixel is ((c0+c1)+c2)+c3. */
+int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
+               uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+               uint32_t samps, uint64_t seed, uint32_t flags, int threads,
+               float* out, orc_stats* stats)
+{
+    if (!cam || !out || (!spheres && n) || w == 0 || h == 0 || samps == 0) return 1;
+    if ((uint64_t)w * h > 0xFFFFFFFFull) return 1;
+    if ((uint64_t)row_begin + row_count > h) return 1;
+    if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return 1;
+    uint64_t tot_b = 0, tot_k = 0;
+    const uint32_t spp = 4 * samps;                                   /* :286 */
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : tot_b, tot_k)
+#endif
+    for (int64_t r = 0; r < (int64_t)row_count; ++r) {               /* :317 */
+        trace_ctx tc;
+        tc.sph = spheres; tc.n = n; tc.zero_cut = !(flags & ORC_FLAG_NO_ZERO_WEIGHT_CUT);
+        tc.bounces = 0; tc.depth_kills = 0;
+        const uint32_t py = row_begin + (uint32_t)r;
+        for (uint32_t px = 0; px < w; ++px) {                         /* :296 */
+            const uint32_t pixel_idx = py * w + px;                   /* :298 */
+            f3 cell[4];
+            for (uint32_t sy = 0; sy < 2; ++sy)                       /* :299 */
+                for (uint32_t sx = 0; sx < 2; ++sx) {                 /* :301 */
+                    const uint32_t g = sy * 2 + sx;                   /* :303 */
+                    f3 acc = mk(0, 0, 0);
+                    for (uint32_t s = 0; s < samps; ++s) {            /* :304 */
+                        const uint32_t index_in_pixel = g * samps + s; /* :306 */
+                        uint32_t k0, k1;
+                        orc_sample_keys(seed, pixel_idx, index_in_pixel, &k0, &k1);
+                        const float u1 = orc_rng_uniform(k0, k1, CTR_CAM(0));
+                        const float u2 = orc_rng_uniform(k0, k1, CTR_CAM(1));
+                        path_t p;
+                        camera_ray(cam, w, h, px, py, sx, sy, u1, u2, &p.o, &p.d);
+                        p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; /* :338-339 */
+                        trace_sample(&tc, p, k0, k1, &acc);
+                    }
+                    cell[g] = acc;
+                }
+            f3 c = add(add(add(cell[0], cell[1]), cell[2]), cell[3]);
+            if (flags & ORC_FLAG_NORMALISE) c = scl(c, 1.0f / (float)spp); /* :360, operator/= */
+            st(out + ((size_t)r * w + px) * 3, c);
+        }
+        tot_b += tc.bounces; tot_k += tc.depth_kills;
+    }
+    if (stats) {
+        stats->samples = (uint64_t)row_count * w * spp;
+        stats->bounces = tot_b;
+        stats->max_depth_kills = tot_k;
+    }
+    return 0;
+}
