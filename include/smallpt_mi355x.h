@@ -71,10 +71,12 @@ typedef struct spt_stats {
     uint64_t samples;        /* camera paths traced (= rows*w*spp)                          */
     uint64_t bounces;        /* closest-hit queries executed (= intersectGlobalSpheres calls) */
     uint64_t max_depth_kills;/* paths cut by the SPT_MAX_DEPTH guard                          */
-    float    kernel_ms;      /* HIP-event time of the render kernel on its stream             */
+    float    kernel_ms;      /* HIP-event time of the path-tracing megakernel on its stream   */
+    float    finalize_ms;    /* HIP-event time of the cell-fold/normalise/store kernel        */
     float    total_ms;       /* host wall time of the call (spt_render only; incl. D2H copy)  */
     uint32_t grid_blocks;    /* launch geometry actually used                                 */
     uint32_t block_threads;
+    uint32_t pad;
 } spt_stats;
 
 #define SPT_FLAG_NORMALISE 1u  /* divide by spp (cpuRender); otherwise return the raw sum (render()) */

@@ -22,8 +22,8 @@ class SptCamera(C.Structure):
 
 class SptStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("bounces", C.c_uint64), ("max_depth_kills", C.c_uint64),
-                ("kernel_ms", C.c_float), ("total_ms", C.c_float),
-                ("grid_blocks", C.c_uint32), ("block_threads", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
+                ("grid_blocks", C.c_uint32), ("block_threads", C.c_uint32), ("pad", C.c_uint32)]
 
 
 # every symbol include/smallpt_mi355x.h declares: name -> (restype, argtypes)

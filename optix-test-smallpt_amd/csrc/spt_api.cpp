@@ -36,7 +36,7 @@ struct spt_ctx {
     int device = 0;
     int cu_count = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;
     // scene
     uint32_t n = 0;
     float4* d_geom = nullptr;
@@ -118,6 +118,7 @@ int spt_create(int device_id, spt_ctx** out)
     c->cu_count = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_mid)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
     void* p = nullptr;
     if ((e = hipMalloc(&p, 32)) != hipSuccess) return bail("hipMalloc", e);
@@ -138,6 +139,7 @@ void spt_destroy(spt_ctx* c)
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -261,6 +263,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 32, st));
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
     SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, st));
+    SPT_HIP(c, hipEventRecord(c->ev_mid, st));
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
     SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
     SPT_HIP(c, hipEventRecord(c->ev_stop, st));
@@ -278,8 +281,10 @@ int spt_sync(spt_ctx* c, spt_stats* stats)
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) {
         SPT_HIP(c, hipEventSynchronize(c->ev_stop));
-        float ms = 0.f;
-        SPT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        float ms = 0.f, fms = 0.f;
+        SPT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_mid));
+        SPT_HIP(c, hipEventElapsedTime(&fms, c->ev_mid, c->ev_stop));
+        c->last.finalize_ms = fms;
         unsigned long long ctr[2] = {0, 0};
         SPT_HIP(c, hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
         c->last.kernel_ms = ms;

@@ -30,7 +30,7 @@ def smallpt_camera(w, h):
 
 def _stats_dict(st):
     return {"samples": int(st.samples), "bounces": int(st.bounces), "max_depth_kills": int(st.max_depth_kills),
-            "kernel_ms": float(st.kernel_ms), "total_ms": float(st.total_ms),
+            "kernel_ms": float(st.kernel_ms), "finalize_ms": float(st.finalize_ms), "total_ms": float(st.total_ms),
             "grid_blocks": int(st.grid_blocks), "block_threads": int(st.block_threads)}
 
 

@@ -1,0 +1,7 @@
+import pytest
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke():
+    import __graft_entry__ as g
+    g.smoke()

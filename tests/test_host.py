@@ -1,0 +1,100 @@
+"""CPU tests of the host logic: scene tables, JSON scene file, row partition, and the N>1 assembly path
+(world_size 2, gloo) with the oracle standing in for the per-rank renderer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cornell9_table(pkg):
+    s = pkg.cornell9()
+    assert len(s) == 9 and s.dtype.itemsize == 48
+    assert [int(r) for r in s["refl"]] == [0, 0, 0, 0, 0, 0, 1, 2, 0]          # smallpt.cpp:38-46
+    assert np.allclose(s[6]["center"], (27, 16.5, 47)) and s[6]["radius"] == 16.5
+    assert np.all(s[8]["emission"] == 1) and np.all(s[8]["color"] == 0) and np.all(s[3]["color"] == 0)
+    assert np.allclose(s[7]["color"], .999)
+    assert np.all(pkg.cornell9(12.0)[8]["emission"] == 12)
+
+
+def test_random_spheres_is_deterministic(pkg):
+    a, b = pkg.random_spheres(1024, 1024), pkg.random_spheres(1024, 1024)
+    assert a.tobytes() == b.tobytes() and len(a) == 1024
+    assert np.array_equal(a[:7], pkg.cornell9()[[0, 1, 2, 3, 4, 5, 8]])
+    r = a[7:]
+    assert r["radius"].min() >= 0.5 and r["radius"].max() <= 2.5
+    assert r["color"].min() >= .25 and r["color"].max() <= .95 and not r["emission"].any()
+    frac = np.bincount(r["refl"], minlength=3) / len(r)
+    assert abs(frac[0] - .70) < .05 and abs(frac[1] - .15) < .04 and abs(frac[2] - .15) < .04
+    # frozen first random sphere (SplitMix64(1024))
+    assert float(a[7]["radius"]) == 1.0324302911758423 and float(a[7]["center"][0]) == 90.30392456054688
+    assert a.tobytes() != pkg.random_spheres(1024, 1).tobytes()
+
+
+def test_json_scene_roundtrip(pkg):
+    s = pkg.random_spheres(40, 5)
+    text = pkg.spheres_to_json(s, camera={"origin": [50, 52, 295.6], "direction": [0, -0.042612, -1], "fov": 0.5135, "push": 140})
+    back, cam = pkg.spheres_from_json(text)
+    assert back.tobytes() == s.tobytes() and cam["push"] == 140
+    assert '"refl": "DIFF"' in text
+
+
+def test_row_band_partition():
+    from optix_test_smallpt_amd.distributed import row_band
+    for h in (1, 7, 768, 4096, 1000):
+        for world in (1, 2, 3, 4, 8):
+            bands = [row_band(h, world, r) for r in range(world)]
+            assert bands[0][0] == 0 and sum(c for _, c in bands) == h
+            for (b0, c0), (b1, _) in zip(bands, bands[1:]):
+                assert b0 + c0 == b1
+            counts = [c for _, c in bands]
+            assert max(counts) - min(counts) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, samps, seed, outfile):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import optix_test_smallpt_amd as pkg
+    import oracle_binding as orc
+    from optix_test_smallpt_amd.distributed import render_distributed
+    scene = pkg.cornell9()
+
+    def band(begin, count):          # the oracle stands in for the HIP band renderer on CPU
+        img, _ = orc.render(scene, w, h, samps, seed=seed, normalise=True, row_begin=begin, row_count=count, threads=2)
+        return torch.from_numpy(img)
+
+    full = render_distributed(band, w, h)
+    if rank == 0:
+        np.save(outfile, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h", [24, 25])      # even and uneven bands
+def test_gloo_world2_row_tiling_matches_single(pkg, oracle, tmp_path, h):
+    w, samps, seed = 20, 1, 13
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(2, _free_port(), w, h, samps, seed, out), nprocs=2, join=True)
+    got = np.load(out)
+    ref, _ = oracle.render(pkg.cornell9(), w, h, samps, seed=seed, normalise=True)
+    assert got.shape == (h, w, 3) and np.array_equal(got, ref)
