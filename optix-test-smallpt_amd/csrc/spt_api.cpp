@@ -238,6 +238,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     std::memcpy(P.cam_cx, cam->cx, 12); std::memcpy(P.cam_cy, cam->cy, 12);
     P.cam_push = cam->push;
     P.w = w; P.h = h; P.row_begin = row_begin; P.row_count = row_count;
+    P.inv_w = 1.0 / (double)w; P.inv_h = 1.0 / (double)h;
     P.samps = samps; P.ntasks = (uint32_t)ntasks;
     P.s0 = mix32((uint32_t)seed + 0x243F6A88u);
     P.s1 = mix32((uint32_t)(seed >> 32) ^ P.s0 ^ 0x85A308D3u);

@@ -25,10 +25,35 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b)
 {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// ---- correctly rounded sqrtf without the compiler's generic wrapper -------------------------------------
+// v_sqrt_f32 is within 1 ulp; the two FMA residuals pick between s-1ulp, s, s+1ulp exactly (the same
+// fix-up LLVM emits for sqrtf, minus its unconditional 2^32 pre-scaling and class check).  Exhaustively
+// checked on the CPU for every binary32 mantissa: tools/verify_exact_math.c.  x = 0, +inf, NaN and x < 0
+// fall through with the IEEE result (0, inf, NaN, NaN).
+__device__ __forceinline__ float sqrt_fix(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+    const float su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x);
+    const float ru = __builtin_fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    return s;
+}
+// General form: for 0 < x < 2^-96 the residuals would underflow, so those (practically never occurring)
+// inputs take the compiler's scaled sequence.  One integer compare covers the range test.
+__device__ __forceinline__ float sqrt_exact(float x)
+{
+    float s = sqrt_fix(x);
+    if (__builtin_expect((__float_as_uint(x) - 1u) < (0x0F800000u - 1u), 0)) s = __builtin_sqrtf(x);
+    return s;
+}
+
 // optix normalize(): v * (1.0f / sqrtf(dot(v, v)))
 __device__ __forceinline__ f3 normalize(f3 v)
 {
-    float inv = 1.0f / __builtin_sqrtf(dot(v, v));
+    float inv = 1.0f / sqrt_exact(dot(v, v));
     return v * inv;
 }
 
@@ -41,7 +66,21 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     return x;
 }
 constexpr uint32_t kGolden = 0x9E3779B9u;
-// ctr = [31:29] branch | [28] camera | [27:2] depth | [1:0] dimension
+// ctr = [31:29] branch | [28] camera | [27:2] depth | [1:0] dimension.
+// The kernel keeps rbase = k0 + ((branch << 29) | (depth << 2)) * kGolden per path (one add per bounce)
+// and draws dimension j from rbase + j * kGolden: identical to k0 + ctr * kGolden mod 2^32.
+__device__ __forceinline__ uint32_t rng_base(uint32_t k0, uint32_t branch, uint32_t depth)
+{
+    return k0 + ((branch << 29) | (depth << 2)) * kGolden;
+}
+__device__ __forceinline__ float rng_draw(uint32_t x, uint32_t k1)
+{
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x += k1;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return (float)(x >> 8) * 0x1p-24f;
+}
 __device__ __forceinline__ float rng_uniform(uint32_t k0, uint32_t k1, uint32_t ctr)
 {
     uint32_t x = k0 + ctr * kGolden;

@@ -4,6 +4,9 @@
 #include <stdint.h>
 
 #define SPT_K_MAX_DEPTH 4096u
+#ifndef SPT_RING
+#define SPT_RING 2
+#endif
 
 namespace spt {
 
@@ -13,6 +16,7 @@ struct KParams {
     float cam_push;
     // image / band
     uint32_t w, h, row_begin, row_count;
+    double inv_w, inv_h;     // RN(1/w), RN(1/h) for the exact double division of smallpt.cpp:331-332
     uint32_t samps;          // samples per jitter cell (spp = 4*samps)
     uint32_t ntasks;         // 4 * row_count * w
     // RNG seed hashes (D7), computed on the host once per render
