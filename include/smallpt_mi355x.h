@@ -114,9 +114,13 @@ int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uin
 /* Waits for the last launch of this context and fills stats (may be NULL). */
 int  spt_sync(spt_ctx* ctx, spt_stats* stats);
 
-/* Tuning knobs (0 = default).  waves_per_cu caps the persistent grid; variant selects a kernel
- * build variant for A/B runs.  Results never depend on these. */
+/* Tuning knobs (0 = default).  blocks_per_cu caps the persistent grid; variant bits 0..7 = number of
+ * waiting lanes that triggers a wave's glass-shading pass (0 = default 8), bit 8 = instrumented kernel
+ * build (see spt_diag).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
+/* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
+ * out15[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters. */
+int  spt_diag(spt_ctx* ctx, unsigned long long* out15);
 
 /* Image output helpers kept from the reference: toInt (smallpt.cpp:52), flipY (:125-134) and the
  * ASCII P3 writer (:136-142).  rgb is w*h*3 floats, row 0 = bottom; the file gets the flipped image. */

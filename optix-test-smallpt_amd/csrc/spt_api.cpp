@@ -42,6 +42,7 @@ struct spt_ctx {
     float4* d_geom = nullptr;
     float4* d_mat = nullptr;
     uint32_t scene_cap = 0;
+    bool tiny_radius = false;      // some r*r < 2^-60: the hot-loop sqrt keeps its small-argument guard
     // scratch
     float4* d_cells = nullptr;
     size_t cells_cap = 0;          // in float4
@@ -55,6 +56,7 @@ struct spt_ctx {
     // last launch
     bool pending = false;
     spt_stats last{};
+    unsigned long long diag[15] = {};   // DIAG build only: phase wave-times and lane counts
     std::string error;
 
     int fail(const char* fmt, ...)
@@ -121,7 +123,7 @@ int spt_create(int device_id, spt_ctx** out)
     if ((e = hipEventCreate(&c->ev_mid)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
     void* p = nullptr;
-    if ((e = hipMalloc(&p, 32)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&p, 256)) != hipSuccess) return bail("hipMalloc", e);
     c->d_queue = static_cast<uint32_t*>(p);
     c->d_counters = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + 16);
     *out = c;
@@ -190,6 +192,9 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
     SPT_HIP(c, hipMemcpy(c->d_geom, geom.data(), sizeof(float4) * cap, hipMemcpyHostToDevice));
     SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
     c->n = n;
+    c->tiny_radius = false;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!(s[i].radius * s[i].radius >= 0x1p-60f)) c->tiny_radius = true;
     return 0;
 }
 
@@ -220,7 +225,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     if (row_count == 0 || (uint64_t)row_begin + row_count > h) return c->fail("spt_render_rows_device: row band [%u,+%u) outside image height %u", row_begin, row_count, h);
     if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: spp overflows 32 bits");
     const uint64_t npix = (uint64_t)row_count * w;
-    if (npix * 4 > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: band has more than 2^30 pixels; split it");
+    if (npix * 4 > 0xF0000000ull) return c->fail("spt_render_rows_device: band has more than 15*2^26 pixels; split it");
     if (!c->d_geom) return c->fail("spt_render_rows_device: no scene set (call spt_set_scene)");
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) { SPT_HIP(c, hipEventSynchronize(c->ev_stop)); }
@@ -240,6 +245,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     P.w = w; P.h = h; P.row_begin = row_begin; P.row_count = row_count;
     P.inv_w = 1.0 / (double)w; P.inv_h = 1.0 / (double)h;
     P.samps = samps; P.ntasks = (uint32_t)ntasks;
+    P.park_threshold = (c->variant & 0xFFu) ? (c->variant & 0xFFu) : 8u;
     P.s0 = mix32((uint32_t)seed + 0x243F6A88u);
     P.s1 = mix32((uint32_t)(seed >> 32) ^ P.s0 ^ 0x85A308D3u);
     P.n = c->n; P.n_pad = c->n ? c->n : 1;
@@ -261,9 +267,9 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     if (blocks < 1) blocks = 1;
 
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 32, st));
+    SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
-    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, st));
+    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, c->tiny_radius ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, st));
     SPT_HIP(c, hipEventRecord(c->ev_mid, st));
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
     SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
@@ -291,6 +297,7 @@ int spt_sync(spt_ctx* c, spt_stats* stats)
         c->last.kernel_ms = ms;
         c->last.bounces = ctr[0];
         c->last.max_depth_kills = ctr[1];
+        if (c->variant & 0x100u) SPT_HIP(c, hipMemcpy(c->diag, c->d_counters + 2, sizeof c->diag, hipMemcpyDeviceToHost));
         c->pending = false;
     }
     if (stats) *stats = c->last;
@@ -319,6 +326,14 @@ int spt_render(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h, uint32
     if (int rc = spt_sync(c, nullptr)) return rc;
     c->last.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = c->last;
+    return 0;
+}
+
+// Diagnostic (tuning variant bit 8): per-phase wave-time sums [0..7], iterations, lane counts of the last launch.
+int spt_diag(spt_ctx* c, unsigned long long* out15)
+{
+    if (!c || !out15) return 1;
+    std::memcpy(out15, c->diag, sizeof c->diag);
     return 0;
 }
 

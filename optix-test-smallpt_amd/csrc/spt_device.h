@@ -50,10 +50,30 @@ __device__ __forceinline__ float sqrt_exact(float x)
     return s;
 }
 
+// ---- correctly rounded 1.0f / y --------------------------------------------------------------------------
+// v_rcp_f32 (1 ulp) + two FMA Newton steps give RN(1/y) for every binary32 y whose mantissa is not all
+// ones (Markstein; enumerated for all 2^23 mantissas in tools/verify_exact_math.c).  The all-ones mantissa
+// and exponents where the residual could under/overflow take the compiler's IEEE division (rare branch).
+__device__ __forceinline__ float rcp_exact(float y)
+{
+    float r = __builtin_amdgcn_rcpf(y);
+    float e = __builtin_fmaf(-y, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-y, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const uint32_t u = __float_as_uint(y);
+    // safe range: 2^-100 <= y < 2^100 (positive, normal) and mantissa != 0x7FFFFF
+    const bool slow = ((u - 0x0D800000u) >= (0x71800000u - 0x0D800000u)) || ((u & 0x7FFFFFu) == 0x7FFFFFu);
+    if (__builtin_expect(slow, 0)) r = 1.0f / y;
+    return r;
+}
+
 // optix normalize(): v * (1.0f / sqrtf(dot(v, v)))
+template <bool GUARD = true>
 __device__ __forceinline__ f3 normalize(f3 v)
 {
-    float inv = 1.0f / sqrt_exact(dot(v, v));
+    const float q = dot(v, v);
+    const float inv = rcp_exact(GUARD ? sqrt_exact(q) : sqrt_fix(q));
     return v * inv;
 }
 

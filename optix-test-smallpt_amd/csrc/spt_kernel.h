@@ -4,9 +4,6 @@
 #include <stdint.h>
 
 #define SPT_K_MAX_DEPTH 4096u
-#ifndef SPT_RING
-#define SPT_RING 2
-#endif
 
 namespace spt {
 
@@ -19,6 +16,7 @@ struct KParams {
     double inv_w, inv_h;     // RN(1/w), RN(1/h) for the exact double division of smallpt.cpp:331-332
     uint32_t samps;          // samples per jitter cell (spp = 4*samps)
     uint32_t ntasks;         // 4 * row_count * w
+    uint32_t park_threshold; // glass-shading pass runs when this many lanes of a wave wait for it
     // RNG seed hashes (D7), computed on the host once per render
     uint32_t s0, s1;
     // scene tables (device memory)
@@ -28,12 +26,12 @@ struct KParams {
     // outputs
     float4* cells;           // ntasks cell sums
     uint32_t* queue;         // task queue head (zeroed before launch)
-    unsigned long long* counters;  // [0] bounces, [1] depth-cap kills
+    unsigned long long* counters;  // [0] bounces, [1] depth-cap kills, [2..16] DIAG phase times / lane counts
 };
 
 }  // namespace spt
 
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds);
-extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, hipStream_t stream);
+extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, hipStream_t stream);
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream);
 extern "C" int spt_k_block_threads(void);

@@ -21,24 +21,76 @@ constexpr int kBlock = 256;
 constexpr float kInf = 1e20f;   // maths.h:16
 constexpr float kEps = 1e-4f;   // scene.cpp:133
 
-// Per-thread LDS scratch, laid out [slot][field][thread] so that every access is conflict-free:
-//   stack: pending transmitted children of the glass split (smallpt.cpp:252), <= 3 per lane
-//   ring : pre-generated camera rays of the lane's current task (path regeneration queue)
+// Per-thread LDS stack of pending transmitted children of the glass split (smallpt.cpp:252), <= 3 per
+// lane, laid out [entry][field][thread] so that every access is conflict-free.
 constexpr int kStackFields = 10;   // o.xyz d.xyz w.xyz (depth | branch << 16)
 constexpr int kStackEntries = 3;
-constexpr int kRingFields = 6;     // dd.xyz, 1/|dd|, k0, k1
-constexpr int kRing = SPT_RING;    // ring slots per lane
+constexpr int kChunk = 64;         // task ids fetched from the global queue per atomic
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-template <bool MAT_LDS>
+// One pre-generated camera ray (path regeneration queue entry): un-normalised direction, 1/|dd|, RNG keys.
+struct CamRay { f3 dd; float inv; uint32_t k0, k1; };
+
+// Per-lane path state.
+struct Path {
+    f3 o, d, w;
+    uint32_t depth, branch, rbase;   // rbase = k0 + ctr(branch, depth, 0) * golden (D7)
+};
+
+// shadePaths body up to the material switch (smallpt.cpp:170-198): hit point, normal, emission, Russian
+// roulette.  Returns false if the path dies in the roulette.
+template <bool GUARD>
+__device__ __forceinline__ bool shade_common(const Path& p, float t, const float4 gh, const float4 me, const float4 mc,
+                                             const float4* mats, uint32_t inst, uint32_t k1, f3& acc,
+                                             f3& hx, f3& n, f3& nl, f3& f)
+{
+    hx = p.o + p.d * t;                                                    // scene.cpp:137
+    n = normalize<GUARD>(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));       // scene.cpp:124
+    nl = dot(n, p.d) < 0 ? n : neg(n);                                     // :174 (D2)
+    f = mk(mc.x, mc.y, mc.z);                                              // :175
+    acc = acc + p.w * mk(me.x, me.y, me.z);                                // :179 (D4)
+    if (p.depth > 5) {                                                     // :188 (D5)
+        if (rng_draw(p.rbase, k1) < mc.w) {
+            const float4 mf = mats[3 * inst + 2];                          // color * (1/pmax)
+            f = mk(mf.x, mf.y, mf.z);                                      // :192
+        } else {
+            return false;                                                  // :196
+        }
+    }
+    return true;
+}
+
+// extend() smallpt.cpp:120-123 + D18 depth cap + zero-weight cut.  Returns whether the path continues.
+__device__ __forceinline__ bool extend(Path& p, f3 no, f3 nd, f3 nf, uint32_t& nkill)
+{
+    p.w = p.w * nf;
+    p.o = no; p.d = nd;
+    ++p.depth;
+    p.rbase += 4u * kGolden;
+    if (p.depth >= SPT_K_MAX_DEPTH) { ++nkill; return false; }
+    return !(p.w.x == 0.f && p.w.y == 0.f && p.w.z == 0.f);
+}
+
+// DIAG builds add s_memtime stamps around the phases and report per-phase wave-time sums (diagnostic only;
+// selected by spt_set_tuning variant bit 8, never timed as the product kernel).
+#define SPT_STAMP(slot)                                                        \
+    if (DIAG) {                                                                \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();         \
+        tsum[slot] += now__ - tlast;                                           \
+        tlast = now__;                                                         \
+    }
+
+template <bool MAT_LDS, bool GUARD, bool DIAG>
 __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
 {
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long iters = 0, lanes_d1 = 0, lanes_d2 = 0, lanes_d3 = 0, runs_d3 = 0, runs_c1 = 0, lanes_c1 = 0;
     extern __shared__ float4 lds[];
     float4* s_geom = lds;                                  // n entries {c.xyz, r*r}
     float4* s_mat = lds + P.n_pad;                         // 3*n entries when MAT_LDS
     float* s_stack = reinterpret_cast<float*>(lds + P.n_pad + (MAT_LDS ? 3 * P.n_pad : 0));
-    float* s_ring = s_stack + kStackEntries * kStackFields * kBlock;
 
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < P.n; i += kBlock) {
@@ -58,43 +110,60 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
     const f3 cam_cy = mk(P.cam_cy[0], P.cam_cy[1], P.cam_cy[2]);
 
     // per-lane persistent state
-    bool alive = false;          // a path is in flight
+    bool alive = false;          // a path is in flight (possibly parked)
+    bool parked = false;         // hit a REFR sphere; waits for the wave's next glass-shading pass
     bool task_valid = false, queue_empty = false;
     uint32_t task = 0, sp = 0;
     uint32_t s_gen = P.samps;    // next sample of the task to generate a camera ray for
-    uint32_t rcount = 0, rhead = 0;   // camera-ray ring: entries ready, index of the oldest
-    uint32_t px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0, rbase = 0;
-    f3 o = mk(0, 0, 0), d = mk(0, 0, 1), w = mk(0, 0, 0), acc = mk(0, 0, 0);
-    uint32_t depth = 0, branch = 0;
+    uint32_t rcount = 0;         // camera rays ready in the two-entry register queue (ra = oldest)
+    CamRay ra{mk(0, 0, 0), 0.f, 0u, 0u}, rb{mk(0, 0, 0), 0.f, 0u, 0u};
+    uint32_t px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
+    Path p{mk(0, 0, 0), mk(0, 0, 1), mk(0, 0, 0), 0u, 0u, 0u};
+    f3 acc = mk(0, 0, 0);
+    float hit_t = 0.f;           // closest hit of the current bounce (kept while parked)
+    uint32_t hit_inst = 0;
     uint32_t nbounce = 0, nkill = 0;
+    uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform: this wave's private range of task ids
 
     auto stack_at = [&](uint32_t e, int f) -> float& { return s_stack[(e * kStackFields + f) * kBlock + tid]; };
-    auto ring_at = [&](uint32_t e, int f) -> float& { return s_ring[(e * kRingFields + f) * kBlock + tid]; };
 
     for (;;) {
+        SPT_STAMP(7)
         // ---- phase A: resume a pending transmitted child (smallpt.cpp:252) ----
         if (!alive && sp > 0) {
             --sp;
-            o = mk(stack_at(sp, 0), stack_at(sp, 1), stack_at(sp, 2));
-            d = mk(stack_at(sp, 3), stack_at(sp, 4), stack_at(sp, 5));
-            w = mk(stack_at(sp, 6), stack_at(sp, 7), stack_at(sp, 8));
+            p.o = mk(stack_at(sp, 0), stack_at(sp, 1), stack_at(sp, 2));
+            p.d = mk(stack_at(sp, 3), stack_at(sp, 4), stack_at(sp, 5));
+            p.w = mk(stack_at(sp, 6), stack_at(sp, 7), stack_at(sp, 8));
             const uint32_t db = __float_as_uint(stack_at(sp, 9));
-            depth = db & 0xFFFFu; branch = db >> 16;
-            rbase = rng_base(k0, branch, depth);
+            p.depth = db & 0xFFFFu; p.branch = db >> 16;
+            p.rbase = rng_base(k0, p.branch, p.depth);
             alive = true;
         }
+        SPT_STAMP(0)
         // ---- phase B: task completion + wave-aggregated fetch from the global queue ----
-        const bool idle = !alive && rcount == 0;                 // (sp == 0 here: phase A would have popped)
-        const bool need_task = idle && s_gen == P.samps && !queue_empty;
+        const bool need_task = !alive && rcount == 0 && s_gen == P.samps && !queue_empty;   // sp == 0 here
         const unsigned long long need_mask = __ballot(need_task);
         if (need_mask != 0ull) {
             if (need_task && task_valid) P.cells[task] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            // Tasks are handed out from a wave-private chunk of kChunk consecutive task ids; only the chunk
+            // refill touches the global queue word (one device-scope atomic per kChunk tasks per wave: a
+            // per-task atomic saturates the single queue word at ~90 dequeues/us, MI355X_MICROARCH.md "dequeue").
             const uint32_t cnt = (uint32_t)__popcll(need_mask);
-            const int leader = __ffsll((long long)need_mask) - 1;
-            uint32_t base = 0;
-            if ((int)lane_id() == leader) base = atomicAdd(P.queue, cnt);
-            base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
             const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane_id()) - 1ull));
+            const uint32_t avail = chunk_end - chunk_next;            // wave-uniform
+            uint32_t base_old = chunk_next, base_new = 0;
+            if (cnt > avail) {
+                const int leader = __ffsll((long long)need_mask) - 1;
+                uint32_t nb = 0;
+                if ((int)lane_id() == leader) nb = atomicAdd(P.queue, (uint32_t)kChunk);
+                base_new = __builtin_amdgcn_readfirstlane(__shfl(nb, leader));
+                chunk_next = base_new + (cnt - avail);
+                chunk_end = base_new + (uint32_t)kChunk;
+            } else {
+                chunk_next += cnt;
+            }
+            const uint32_t base = rank < avail ? base_old : base_new - avail;
             if (need_task) {
                 task = base + rank;
                 task_valid = task < P.ntasks;
@@ -114,25 +183,26 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 }
             }
         }
+        SPT_STAMP(1)
         // ---- phase C1: batched path regeneration (smallpt.cpp:325-340).  Runs only when some lane is out
-        // of camera rays; then EVERY lane with a free ring slot generates one, so the ~150-instruction
+        // of camera rays; then EVERY lane with a free queue slot generates one, so the ~130-instruction
         // generator executes with most lanes active instead of once per terminated path. ----
         const bool starved = !alive && rcount == 0 && task_valid && s_gen < P.samps;
         if (__ballot(starved) != 0ull) {
-            if (task_valid && s_gen < P.samps && rcount < (uint32_t)kRing) {
+            if (DIAG) { ++runs_c1; lanes_c1 += __popcll(__ballot(task_valid && s_gen < P.samps && rcount < 2u)); }
+            if (task_valid && s_gen < P.samps && rcount < 2u) {
                 const uint32_t index_in_pixel = cell * P.samps + s_gen;      // smallpt.cpp:306
-                const uint32_t gk0 = mix32(p0 ^ (index_in_pixel * kGolden));
-                const uint32_t gk1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
-                const float u1 = rng_draw(gk0 + ((1u << 28) | 0u) * kGolden, gk1);
-                const float u2 = rng_draw(gk0 + ((1u << 28) | 1u) * kGolden, gk1);
+                CamRay e;
+                e.k0 = mix32(p0 ^ (index_in_pixel * kGolden));
+                e.k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
+                const float u1 = rng_draw(e.k0 + ((1u << 28) | 0u) * kGolden, e.k1);
+                const float u2 = rng_draw(e.k0 + ((1u << 28) | 1u) * kGolden, e.k1);
                 // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt fix-up is exact here
                 const float r1 = 2 * u1;
-                const float a1 = r1 < 1 ? r1 : 2 - r1;
-                const float q1 = sqrt_fix(a1);
+                const float q1 = sqrt_fix(r1 < 1 ? r1 : 2 - r1);
                 const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
                 const float r2 = 2 * u2;
-                const float a2 = r2 < 1 ? r2 : 2 - r2;
-                const float q2 = sqrt_fix(a2);
+                const float q2 = sqrt_fix(r2 < 1 ? r2 : 2 - r2);
                 const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                 const uint32_t sx = cell & 1u, sy = cell >> 1;
                 // :331-332 in double as in the reference.  a / w is evaluated as q0 = a*y, q = fma(fma(-q0,w,a), y, q0)
@@ -143,139 +213,160 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 const double qx = __builtin_fma(__builtin_fma(-qx0, (double)P.w, tx), P.inv_w, qx0);
                 const double qy = __builtin_fma(__builtin_fma(-qy0, (double)P.h, ty), P.inv_h, qy0);
                 const float ax = (float)(qx - .5), ay = (float)(qy - .5);
-                const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
-                const float inv = 1.0f / sqrt_exact(dot(dd, dd));
-                uint32_t slot = rhead + rcount;
-                if (slot >= (uint32_t)kRing) slot -= (uint32_t)kRing;
-                ring_at(slot, 0) = dd.x; ring_at(slot, 1) = dd.y; ring_at(slot, 2) = dd.z; ring_at(slot, 3) = inv;
-                ring_at(slot, 4) = __uint_as_float(gk0); ring_at(slot, 5) = __uint_as_float(gk1);
+                e.dd = cam_cx * ax + cam_cy * ay + cam_d;
+                e.inv = rcp_exact(sqrt_exact(dot(e.dd, e.dd)));
+                if (rcount == 0) ra = e; else rb = e;
                 ++rcount;
                 ++s_gen;
             }
         }
-        // ---- phase C2: start the next camera path from the ring (cheap: 6 LDS reads + 9 VALU) ----
+        SPT_STAMP(2)
+        // ---- phase C2: start the next camera path from the queue (registers only) ----
         if (!alive && rcount > 0) {
-            const f3 dd = mk(ring_at(rhead, 0), ring_at(rhead, 1), ring_at(rhead, 2));
-            const float inv = ring_at(rhead, 3);
-            k0 = __float_as_uint(ring_at(rhead, 4));
-            rbase = k0;                                          // k0 + ctr(branch 0, depth 0) * golden
-            k1 = __float_as_uint(ring_at(rhead, 5));
-            o = cam_o + dd * P.cam_push;                                                // :333
-            d = dd * inv;                                                               // normalize(d)
-            w = mk(1, 1, 1); depth = 0; branch = 0;                                      // :338-339
-            ++rhead; if (rhead >= (uint32_t)kRing) rhead = 0;
+            k0 = ra.k0; k1 = ra.k1;
+            p.o = cam_o + ra.dd * P.cam_push;                                           // :333
+            p.d = ra.dd * ra.inv;                                                       // normalize(d)
+            p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; p.rbase = k0;                  // :338-339
+            ra = rb;
             --rcount;
             alive = true;
         }
+        SPT_STAMP(3)
         if (__ballot(alive) == 0ull) break;   // no lane has a path, a stack entry, a camera ray, a sample or a task left
 
-        // ---- phase D: one bounce = intersectGlobalSpheres + shadePaths body ----
-        if (alive) {
+        // ---- phase D1: closest hit, smallpt.cpp:54-70 over scene.cpp:129-140 (D1, D16).  Branch-free per
+        // sphere: det < 0 gives sqrt = NaN and every comparison below is false, like the early return. ----
+        bool shade = false;
+        if (alive && !parked) {
             ++nbounce;
-            // closest hit, smallpt.cpp:54-70 over scene.cpp:129-140 (D1, D16).  Branch-free per sphere:
-            // det < 0 gives sqrt = NaN and every comparison below is false, exactly like the early return.
             float nearest = kInf;
             uint32_t inst = 0;
             float4 g = s_geom[0];
             for (uint32_t i = 0; i < P.n; ++i) {
                 const float4 gn = s_geom[i + 1 < P.n ? i + 1 : i];   // prefetch next sphere (wave-uniform LDS broadcast)
-                const f3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);                    // :132
-                const float b = dot(op, d);                                            // :133
+                const f3 op = mk(g.x - p.o.x, g.y - p.o.y, g.z - p.o.z);               // :132
+                const float b = dot(op, p.d);                                          // :133
                 const float det = b * b - dot(op, op) + g.w;                           // :133 (g.w = r*r)
-                const float sd = sqrt_exact(det);                                      // :134
+                const float sd = GUARD ? sqrt_exact(det) : sqrt_fix(det);              // :134
                 const float t1 = b - sd, t2 = b + sd;                                  // :135
                 const float t = t1 > kEps ? t1 : t2;
                 if (t > kEps && t < nearest) { nearest = t; inst = i; }                // :135-136, smallpt.cpp:61
                 g = gn;
             }
-            if (nearest == kInf) {
-                alive = false;                                                         // :168 miss
+            hit_t = nearest; hit_inst = inst;
+            if (nearest == kInf) alive = false;                                        // :168 miss (D13)
+            else shade = true;
+        }
+        SPT_STAMP(4)
+        if (DIAG) { ++iters; lanes_d1 += __popcll(__ballot(shade || (!alive && hit_t == kInf))); lanes_d2 += __popcll(__ballot(shade)); }
+        // ---- phase D2: shadePaths for DIFF / SPEC hits; REFR hits are parked ----
+        if (shade) {
+            const float4 me = mats[3 * hit_inst + 0];         // emission.xyz, refl
+            const int refl = __float_as_int(me.w);
+            if (refl == 2) {
+                parked = true;
             } else {
-                const float4 gh = s_geom[inst];
-                const float4 me = mats[3 * inst + 0];         // emission.xyz, refl
-                const float4 mc = mats[3 * inst + 1];         // color.xyz, pmax
-                const f3 hx = o + d * nearest;                                         // scene.cpp:137
-                const f3 n = normalize(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));     // scene.cpp:124
-                const f3 nl = dot(n, d) < 0 ? n : neg(n);                              // :174 (D2)
-                f3 f = mk(mc.x, mc.y, mc.z);                                           // :175
-                acc = acc + w * mk(me.x, me.y, me.z);                                  // :179 (D4)
-                const int refl = __float_as_int(me.w);
-                bool cont = true;
-                if (depth > 5) {                                                       // :188 (D5)
-                    if (rng_draw(rbase, k1) < mc.w) {
-                        const float4 mf = mats[3 * inst + 2]; // color * (1/pmax)
-                        f = mk(mf.x, mf.y, mf.z);                                      // :192
-                    } else {
-                        cont = false;                                                  // :196
-                    }
-                }
+                const float4 gh = s_geom[hit_inst];
+                const float4 mc = mats[3 * hit_inst + 1];     // color.xyz, pmax
+                f3 hx, n, nl, f;
+                bool cont = shade_common<GUARD>(p, hit_t, gh, me, mc, mats, hit_inst, k1, acc, hx, n, nl, f);
                 if (cont) {
-                    const f3 off = nl * 0.02f;                                         // :172 (D3)
-                    f3 no = hx + off, nd, nf = f;
+                    const f3 no = hx + nl * 0.02f;                                     // :172 (D3)
+                    f3 nd;
                     if (refl == 0) {                                                   // DIFF :208-215
-                        const float u1 = rng_draw(rbase + kGolden, k1);
-                        const float r2 = rng_draw(rbase + 2u * kGolden, k1);
+                        const float u1 = rng_draw(p.rbase + kGolden, k1);
+                        const float r2 = rng_draw(p.rbase + 2u * kGolden, k1);
                         const float r2s = sqrt_fix(r2);                               // r2 in {0} U [2^-24, 1)
                         float sn, cs;
                         sincos2pi(u1, sn, cs);                                          // D17
                         const f3 ww = nl;
-                        // (double)fabs(w.x) > .1  <=>  fabsf(w.x) >= 0.1f  (0.1f is the least float above 0.1)
-                        const f3 uu = normalize(cross(__builtin_fabsf(ww.x) >= 0.1f ? mk(0, 1, 0) : mk(1, 0, 0), ww));
+                        // u = normalize(cross(|w.x| > .1 ? (0,1,0) : (1,0,0), w)), :211.  (double)fabs(w.x) > .1 <=>
+                        // fabsf(w.x) >= 0.1f.  cross((0,1,0),w) = (w.z, 0, -w.x); cross((1,0,0),w) = (0, -w.z, w.y):
+                        // the products with the axis' zeros only contribute signed zeros, which never reach a
+                        // non-zero value or a comparison downstream.
+                        const bool ay = __builtin_fabsf(ww.x) >= 0.1f;
+                        const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
+                        const float s2 = ay ? ww.x : ww.y;
+                        const float qu = ww.z * ww.z + s2 * s2;       // dot(ur, ur) with the zero term dropped
+                        const f3 uu = ur * rcp_exact(sqrt_fix(qu));
                         const f3 vv = cross(ww, uu);
-                        nd = normalize(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix(1 - r2)); // :212
+                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix(1 - r2)); // :212
                     } else {
-                        const f3 rd = d - n * 2.0f * dot(n, d);                        // :218
-                        nd = rd;
-                        if (refl == 2) {                                               // REFR :225-263
-                            const bool into = dot(n, nl) > 0;                          // :225
-                            const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;        // :228
-                            const float ddn = dot(d, nl);                              // :229
-                            const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);       // :230
-                            if (!(cos2t < 0)) {                                        // else TIR :232-236
-                                const f3 tdir = normalize(d * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t)))); // :238
-                                const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);        // :240-242
-                                const float c = 1 - (into ? -ddn : dot(tdir, n));      // :243
-                                const float c2 = c * c;                                // :244
-                                const float Re = R0 + (1 - R0) * c2 * c2 * c;          // :245
-                                const float Tr = 1 - Re;                               // :246
-                                const f3 xin = hx - off;                               // D3
-                                if (depth <= 2) {                                      // :248 split (D6)
-                                    // transmitted child -> LDS stack; reflected child continues (:251-252)
-                                    const f3 tw = w * (f * Tr);
-                                    const bool keep = !(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f);
-                                    if (keep) {
-                                        stack_at(sp, 0) = xin.x; stack_at(sp, 1) = xin.y; stack_at(sp, 2) = xin.z;
-                                        stack_at(sp, 3) = tdir.x; stack_at(sp, 4) = tdir.y; stack_at(sp, 5) = tdir.z;
-                                        stack_at(sp, 6) = tw.x; stack_at(sp, 7) = tw.y; stack_at(sp, 8) = tw.z;
-                                        stack_at(sp, 9) = __uint_as_float((depth + 1u) | ((branch | (1u << depth)) << 16));
-                                        ++sp;
-                                    }
-                                    nf = f * Re;
-                                } else {
-                                    const float Pr = 0.25f + 0.5f * Re;                // :256
-                                    if (rng_draw(rbase + kGolden, k1) < Pr) {
-                                        nf = f * Re * (1.0f / Pr);                     // :259
-                                    } else {
-                                        nf = f * Tr * (1.0f / (1.f - Pr));             // :263
-                                        no = xin; nd = tdir;
-                                    }
-                                }
-                            }
-                        }
+                        nd = p.d - n * 2.0f * dot(n, p.d);                             // SPEC :218-223
                     }
-                    // extend(), smallpt.cpp:120-123, + D18 depth cap + zero-weight cut
-                    w = w * nf;
-                    o = no; d = nd;
-                    ++depth;
-                    rbase += 4u * kGolden;
-                    if (depth >= SPT_K_MAX_DEPTH) { cont = false; ++nkill; }
-                    else if (w.x == 0.f && w.y == 0.f && w.z == 0.f) cont = false;
+                    cont = extend(p, no, nd, f, nkill);
                 }
                 alive = cont;
             }
         }
+        SPT_STAMP(5)
+        // ---- phase D3: glass (REFR, smallpt.cpp:225-263).  Executed for all parked lanes at once when enough
+        // of them wait (or nothing else is left to do), so the ~150-instruction block does not run for one
+        // or two lanes on every iteration. ----
+        {
+            const unsigned long long pm = __ballot(parked);
+            const unsigned long long others = __ballot(alive && !parked);
+            if (pm != 0ull && ((uint32_t)__popcll(pm) >= P.park_threshold || others == 0ull)) {
+                if (DIAG) { ++runs_d3; lanes_d3 += __popcll(pm); }
+                if (parked) {
+                    parked = false;
+                    const float4 gh = s_geom[hit_inst];
+                    const float4 me = mats[3 * hit_inst + 0];
+                    const float4 mc = mats[3 * hit_inst + 1];
+                    f3 hx, n, nl, f;
+                    bool cont = shade_common<GUARD>(p, hit_t, gh, me, mc, mats, hit_inst, k1, acc, hx, n, nl, f);
+                    if (cont) {
+                        const f3 off = nl * 0.02f;                                     // :172 (D3)
+                        f3 no = hx + off, nf = f;
+                        f3 nd = p.d - n * 2.0f * dot(n, p.d);                          // :218 reflRay
+                        const bool into = dot(n, nl) > 0;                              // :225
+                        const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;            // :228
+                        const float ddn = dot(p.d, nl);                                // :229
+                        const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);           // :230
+                        if (!(cos2t < 0)) {                                            // else TIR :232-236
+                            const f3 tdir = normalize<true>(p.d * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t)))); // :238
+                            const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);            // :240-242
+                            const float c = 1 - (into ? -ddn : dot(tdir, n));          // :243
+                            const float c2 = c * c;                                    // :244
+                            const float Re = R0 + (1 - R0) * c2 * c2 * c;              // :245
+                            const float Tr = 1 - Re;                                   // :246
+                            const f3 xin = hx - off;                                   // D3
+                            if (p.depth <= 2) {                                        // :248 split (D6)
+                                // transmitted child -> LDS stack; reflected child continues (:251-252)
+                                const f3 tw = p.w * (f * Tr);
+                                if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
+                                    stack_at(sp, 0) = xin.x; stack_at(sp, 1) = xin.y; stack_at(sp, 2) = xin.z;
+                                    stack_at(sp, 3) = tdir.x; stack_at(sp, 4) = tdir.y; stack_at(sp, 5) = tdir.z;
+                                    stack_at(sp, 6) = tw.x; stack_at(sp, 7) = tw.y; stack_at(sp, 8) = tw.z;
+                                    stack_at(sp, 9) = __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16));
+                                    ++sp;
+                                }
+                                nf = f * Re;
+                            } else {
+                                const float Pr = 0.25f + 0.5f * Re;                    // :256
+                                if (rng_draw(p.rbase + kGolden, k1) < Pr) {
+                                    nf = f * Re * (1.0f / Pr);                         // :259
+                                } else {
+                                    nf = f * Tr * (1.0f / (1.f - Pr));                 // :263
+                                    no = xin; nd = tdir;
+                                }
+                            }
+                        }
+                        cont = extend(p, no, nd, nf, nkill);
+                    }
+                    alive = cont;
+                }
+            }
+        }
+        SPT_STAMP(6)
     }
 
+    if (DIAG && lane_id() == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[2 + i], tsum[i]);
+        atomicAdd(&P.counters[10], iters); atomicAdd(&P.counters[11], lanes_d1); atomicAdd(&P.counters[12], lanes_d2);
+        atomicAdd(&P.counters[13], lanes_d3); atomicAdd(&P.counters[14], runs_d3); atomicAdd(&P.counters[15], runs_c1);
+        atomicAdd(&P.counters[16], lanes_c1);
+    }
     // stats: wave reduction then one atomic per wave
     unsigned long long nb = nbounce, nk = nkill;
     for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nk += __shfl_down(nk, off); }
@@ -305,23 +396,26 @@ __global__ __launch_bounds__(kBlock) void finalize(const float4* __restrict__ ce
 // ---- launch wrappers used by spt_api.cpp ----
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds)
 {
-    return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) +
-           (size_t)(spt::kStackEntries * spt::kStackFields + spt::kRing * spt::kRingFields) * spt::kBlock * 4u;
+    return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) + (size_t)spt::kStackEntries * spt::kStackFields * spt::kBlock * 4u;
 }
 
-extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, hipStream_t stream)
+template <bool M, bool G, bool D = false>
+static hipError_t launch_variant(const spt::KParams* P, uint32_t blocks, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<M, G, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((spt::megakernel<M, G, D>), dim3(blocks), dim3(spt::kBlock), lds, stream, *P);
+    return hipGetLastError();
+}
+
+// guard != 0 selects the build whose hot-loop square roots keep the tiny-argument range check
+// (needed only for scenes with radius < 2^-30; see spt_api.cpp).
+extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, hipStream_t stream)
 {
     const size_t lds = spt_k_lds_bytes(P->n_pad, mat_lds);
-    if (mat_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(spt::megakernel<true>, dim3(blocks), dim3(spt::kBlock), lds, stream, *P);
-    } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(spt::megakernel<false>, dim3(blocks), dim3(spt::kBlock), lds, stream, *P);
-    }
-    return hipGetLastError();
+    if (diag) return mat_lds ? launch_variant<true, false, true>(P, blocks, lds, stream) : launch_variant<false, false, true>(P, blocks, lds, stream);
+    if (mat_lds) return guard ? launch_variant<true, true>(P, blocks, lds, stream) : launch_variant<true, false>(P, blocks, lds, stream);
+    return guard ? launch_variant<false, true>(P, blocks, lds, stream) : launch_variant<false, false>(P, blocks, lds, stream);
 }
 
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream)

@@ -105,6 +105,12 @@ class Renderer:
             FLAG_NORMALISE if normalise else 0, C.c_void_p(out_tensor.data_ptr()),
             C.c_void_p(stream) if stream else None))
 
+    def diag(self):
+        """Phase timings / lane counters of the last launch of the instrumented build (variant bit 8)."""
+        arr = (C.c_uint64 * 15)()
+        self._check(self._lib.spt_diag(self._h, C.byref(arr)))
+        return [int(v) for v in arr]
+
     def sync(self):
         st = SptStats()
         self._check(self._lib.spt_sync(self._h, C.byref(st)))

@@ -41,6 +41,26 @@ __global__ __launch_bounds__(256) void k(float* out, float a0, float b0, unsigne
                 if (OP == 21) asm volatile("v_min3_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(b));
                 if (OP == 22) asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(y[i]));
                 if (OP == 23) asm volatile("v_sub_f32 %0, s20, %0" : "+v"(x[i]));
+                if (OP == 24) asm volatile("v_add_f32 %0, 0x3dcccccd, %0" : "+v"(x[i]));
+                if (OP == 25) asm volatile("v_mul_f32 %0, 2.0, %0" : "+v"(x[i]));
+                if (OP == 26) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x[i]) : "v"(b));
+                if (OP == 27) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(b));
+                if (OP == 28) asm volatile("v_mov_b32 %0, %1" : "=v"(x[i]) : "v"(b));
+                if (OP == 29) asm volatile("v_and_b32 %0, %0, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 30) asm volatile("v_fma_f32 %0, %0, s20, %0" : "+v"(x[i]));
+                if (OP == 31) asm volatile("v_mul_f32 %0, s20, %0" : "+v"(x[i]));
+                if (OP == 32) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(x[i]));
+                if (OP == 33) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 34) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_nop\n\tv_nop" : : "v"(x[i]), "v"(b) : "vcc");
+                if (OP == 35) asm volatile("v_nop");
+                if (OP == 36) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 37) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 38) asm volatile("v_alignbit_b32 %0, %0, %0, 15" : "+v"(y[i]));
+                if (OP == 39) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 40) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 41) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x[i]) : "v"(u0));
+                if (OP == 42) asm volatile("v_rsq_f32 %0, %0" : "+v"(x[i]));
+                if (OP == 43) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(b) : );
                 if (OP == 8) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(y[i]) : "v"(u0));
                 if (OP == 9) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[i]), "v"(b) : "vcc");
                 if (OP == 10) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(y[i]) : "v"(u0));
@@ -94,7 +114,7 @@ void run(const char* name, int waves_per_simd, float* d)
 int main()
 {
     float* d; hipMalloc(&d, 4);
-    for (int w : {2, 4, 8}) {
+    for (int w : {4}) {
         run<0>("v_fma_f32", w, d); run<1>("v_mul_f32", w, d); run<2>("v_add_f32", w, d); run<3>("v_mul_lo_u32", w, d);
         run<4>("v_sqrt_f32", w, d); run<5>("v_rcp_f32", w, d); run<6>("v_xor_b32", w, d); run<7>("v_cndmask_b32", w, d);
         run<8>("v_mad_u32_u24", w, d); run<9>("v_cmp_lt_f32", w, d); run<10>("v_lshl_add_u32", w, d);
@@ -102,6 +122,11 @@ int main()
         run<14>("v_cndmask_e64", w, d); run<15>("v_cmp_e64 sgpr", w, d); run<16>("v_add_u32", w, d); run<17>("v_lshrrev_b32", w, d);
         run<18>("v_cvt_f32_u32", w, d); run<19>("v_max_f32", w, d); run<20>("cmp+nop+cndmask", w, d); run<21>("v_min3_f32", w, d);
         run<22>("v_xor_sdwa", w, d); run<23>("v_sub_f32 sgpr", w, d);
+        run<24>("v_add_f32 literal", w, d); run<25>("v_mul_f32 inline2.0", w, d); run<26>("v_min_f32", w, d); run<27>("v_med3_f32", w, d);
+        run<28>("v_mov_b32", w, d); run<29>("v_and_b32", w, d); run<30>("v_fma_f32 sgpr", w, d); run<31>("v_mul_f32 sgpr", w, d);
+        run<32>("v_cvt_f32_i32", w, d); run<33>("v_sub_u32", w, d); run<34>("v_cmp+2 v_nop (x3)", w, d); run<35>("v_nop", w, d);
+        run<36>("v_bfi_b32", w, d); run<37>("v_xad_u32", w, d); run<38>("v_alignbit_b32", w, d); run<39>("v_mul_u32_u24", w, d);
+        run<40>("v_mul_hi_u32", w, d); run<41>("v_ldexp_f32", w, d); run<42>("v_rsq_f32", w, d);
         printf("\n");
     }
     return 0;
