@@ -1,0 +1,257 @@
+// scene.cpp -- Cornell table, ABI conversion, camera constants and the JSON scene reader/writer.
+// The reference only uses JSON for its GL-thread -> render-thread messages (smallpt.cpp:909-918,981-984);
+// the scene file format is the one SURVEY.md 8(f).1 defines (vectors as 3-number arrays like those messages).
+// A ~150-line recursive-descent reader is used instead of vendoring a 12-kLoC JSON library.
+#include "scene.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+
+namespace spt_host {
+
+Scene cornell9()
+{
+    Scene s;
+    const float3 z = make_float3(0, 0, 0);
+    auto& v = s.spheres;   // Scene: radius, position, emission, color, material (smallpt.cpp:36)
+    v.emplace_back(1e5f, make_float3(1e5f + 1, 40.8f, 81.6f), z, make_float3(.75f, .25f, .25f), DIFF);   // Left :38
+    v.emplace_back(1e5f, make_float3(-1e5f + 99, 40.8f, 81.6f), z, make_float3(.25f, .25f, .75f), DIFF);  // Rght :39
+    v.emplace_back(1e5f, make_float3(50, 40.8f, 1e5f), z, make_float3(.75f, .75f, .75f), DIFF);           // Back :40
+    v.emplace_back(1e5f, make_float3(50, 40.8f, -1e5f + 170), z, z, DIFF);                                // Frnt :41
+    v.emplace_back(1e5f, make_float3(50, 1e5f, 81.6f), z, make_float3(.75f, .75f, .75f), DIFF);           // Botm :42
+    v.emplace_back(1e5f, make_float3(50, -1e5f + 81.6f, 81.6f), z, make_float3(.75f, .75f, .75f), DIFF);  // Top  :43
+    v.emplace_back(16.5f, make_float3(27, 16.5f, 47), z, make_float3(.999f, .999f, .999f), SPEC);         // Mirr :44
+    v.emplace_back(16.5f, make_float3(73, 16.5f, 78), z, make_float3(.999f, .999f, .999f), REFR);         // Glas :45
+    v.emplace_back(600.f, make_float3(50, (float)(681.6 - .27), 81.6f), make_float3(1, 1, 1), z, DIFF);   // Lite :46
+    return s;
+}
+
+std::vector<spt_sphere> to_abi(const std::vector<Sphere>& spheres)
+{
+    std::vector<spt_sphere> out(spheres.size());
+    for (size_t i = 0; i < spheres.size(); ++i) {
+        const Sphere& s = spheres[i];
+        spt_sphere& o = out[i];
+        std::memset(&o, 0, sizeof o);
+        o.center[0] = s.center.x; o.center[1] = s.center.y; o.center[2] = s.center.z;
+        o.radius = s.radius;
+        o.emission[0] = s.material.emission.x; o.emission[1] = s.material.emission.y; o.emission[2] = s.material.emission.z;
+        o.color[0] = s.material.color.x; o.color[1] = s.material.color.y; o.color[2] = s.material.color.z;
+        o.refl = (int32_t)s.material.refl;
+    }
+    return out;
+}
+
+namespace {
+inline float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float3 cross3(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float3 scale3(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float3 normalize3(float3 v) { const float inv = 1.0f / std::sqrt(dot3(v, v)); return scale3(v, inv); }
+}  // namespace
+
+spt_camera make_camera(const CameraDesc& c, uint32_t w, uint32_t h)
+{
+    spt_camera cam;
+    const float3 dir = normalize3(c.direction);                                  // smallpt.cpp:277
+    const float3 cx = make_float3((float)((int)w * c.fov / (int)h), 0, 0);       // :278 (D10)
+    const float3 cy = scale3(normalize3(cross3(cx, dir)), (float)c.fov);         // :279
+    cam.origin[0] = c.origin.x; cam.origin[1] = c.origin.y; cam.origin[2] = c.origin.z;
+    cam.dir[0] = dir.x; cam.dir[1] = dir.y; cam.dir[2] = dir.z;
+    cam.cx[0] = cx.x; cam.cx[1] = cx.y; cam.cx[2] = cx.z;
+    cam.cy[0] = cy.x; cam.cy[1] = cy.y; cam.cy[2] = cy.z;
+    cam.push = c.push;
+    return cam;
+}
+
+// ------------------------------------------------------------------------------------------ JSON reader
+namespace {
+
+struct JValue;
+using JPtr = std::shared_ptr<JValue>;
+struct JValue {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    double num = 0;
+    bool b = false;
+    std::string str;
+    std::vector<JPtr> arr;
+    std::map<std::string, JPtr> obj;
+};
+
+class Parser {
+public:
+    explicit Parser(const std::string& t) : s_(t) {}
+    JPtr parse()
+    {
+        JPtr v = value();
+        ws();
+        if (i_ != s_.size()) fail("trailing characters");
+        return v;
+    }
+
+private:
+    const std::string& s_;
+    size_t i_ = 0;
+
+    [[noreturn]] void fail(const char* what) const
+    {
+        std::ostringstream m;
+        m << "scene JSON: " << what << " at offset " << i_;
+        throw std::runtime_error(m.str());
+    }
+    void ws() { while (i_ < s_.size() && (s_[i_] == ' ' || s_[i_] == '\t' || s_[i_] == '\n' || s_[i_] == '\r')) ++i_; }
+    bool eat(char c) { ws(); if (i_ < s_.size() && s_[i_] == c) { ++i_; return true; } return false; }
+    void expect(char c) { if (!eat(c)) fail("unexpected character"); }
+
+    JPtr value()
+    {
+        ws();
+        if (i_ >= s_.size()) fail("unexpected end");
+        auto v = std::make_shared<JValue>();
+        const char c = s_[i_];
+        if (c == '{') {
+            ++i_; v->kind = JValue::Object;
+            if (eat('}')) return v;
+            do {
+                ws();
+                if (i_ >= s_.size() || s_[i_] != '"') fail("expected object key");
+                std::string k = string();
+                expect(':');
+                v->obj[k] = value();
+            } while (eat(','));
+            expect('}');
+        } else if (c == '[') {
+            ++i_; v->kind = JValue::Array;
+            if (eat(']')) return v;
+            do { v->arr.push_back(value()); } while (eat(','));
+            expect(']');
+        } else if (c == '"') {
+            v->kind = JValue::String; v->str = string();
+        } else if (!s_.compare(i_, 4, "true")) { i_ += 4; v->kind = JValue::Bool; v->b = true;
+        } else if (!s_.compare(i_, 5, "false")) { i_ += 5; v->kind = JValue::Bool;
+        } else if (!s_.compare(i_, 4, "null")) { i_ += 4;
+        } else {
+            const char* b = s_.c_str() + i_;
+            char* e = nullptr;
+            v->num = std::strtod(b, &e);
+            if (e == b) fail("invalid value");
+            v->kind = JValue::Number;
+            i_ += (size_t)(e - b);
+        }
+        return v;
+    }
+    std::string string()
+    {
+        std::string out;
+        ++i_;   // opening quote
+        while (i_ < s_.size() && s_[i_] != '"') {
+            char c = s_[i_++];
+            if (c == '\\') {
+                if (i_ >= s_.size()) fail("bad escape");
+                const char e = s_[i_++];
+                switch (e) {
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case 'u': if (i_ + 4 > s_.size()) fail("bad \\u escape"); out += '?'; i_ += 4; break;
+                default: out += e;
+                }
+            } else out += c;
+        }
+        if (i_ >= s_.size()) fail("unterminated string");
+        ++i_;
+        return out;
+    }
+};
+
+const JValue& member(const JValue& o, const char* key)
+{
+    auto it = o.obj.find(key);
+    if (o.kind != JValue::Object || it == o.obj.end()) throw std::runtime_error(std::string("scene JSON: missing field \"") + key + "\"");
+    return *it->second;
+}
+float3 vec3(const JValue& v, const char* what)
+{
+    if (v.kind != JValue::Array || v.arr.size() != 3) throw std::runtime_error(std::string("scene JSON: \"") + what + "\" must be an array of 3 numbers");
+    for (auto& e : v.arr) if (e->kind != JValue::Number) throw std::runtime_error(std::string("scene JSON: \"") + what + "\" must be an array of 3 numbers");
+    return make_float3((float)v.arr[0]->num, (float)v.arr[1]->num, (float)v.arr[2]->num);
+}
+double number(const JValue& v, const char* what)
+{
+    if (v.kind != JValue::Number) throw std::runtime_error(std::string("scene JSON: \"") + what + "\" must be a number");
+    return v.num;
+}
+
+}  // namespace
+
+Scene load_scene_json(const std::string& text)
+{
+    Parser p(text);
+    JPtr root = p.parse();
+    Scene sc;
+    const JValue& spheres = member(*root, "spheres");
+    if (spheres.kind != JValue::Array) throw std::runtime_error("scene JSON: \"spheres\" must be an array");
+    for (auto& e : spheres.arr) {
+        const JValue& r = member(*e, "refl");
+        Refl_t refl;
+        if (r.kind == JValue::String) {
+            if (r.str == "DIFF") refl = DIFF; else if (r.str == "SPEC") refl = SPEC; else if (r.str == "REFR") refl = REFR;
+            else throw std::runtime_error("scene JSON: refl must be DIFF, SPEC or REFR");
+        } else {
+            const int k = (int)number(r, "refl");
+            if (k < 0 || k > 2) throw std::runtime_error("scene JSON: refl must be 0, 1 or 2");
+            refl = (Refl_t)k;
+        }
+        sc.spheres.emplace_back((float)number(member(*e, "radius"), "radius"), vec3(member(*e, "center"), "center"),
+                                vec3(member(*e, "emission"), "emission"), vec3(member(*e, "color"), "color"), refl);
+    }
+    auto cit = root->obj.find("camera");
+    if (cit != root->obj.end() && cit->second->kind == JValue::Object) {
+        const JValue& c = *cit->second;
+        sc.camera.present = true;
+        if (c.obj.count("origin")) sc.camera.origin = vec3(member(c, "origin"), "origin");
+        if (c.obj.count("direction")) sc.camera.direction = vec3(member(c, "direction"), "direction");
+        if (c.obj.count("fov")) sc.camera.fov = number(member(c, "fov"), "fov");
+        if (c.obj.count("push")) sc.camera.push = (float)number(member(c, "push"), "push");
+    }
+    return sc;
+}
+
+Scene load_scene_file(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open scene file " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return load_scene_json(ss.str());
+}
+
+std::string scene_to_json(const Scene& scene)
+{
+    std::ostringstream o;
+    o.precision(9);   // 9 significant digits round-trip every binary32 value
+    auto v3 = [&](float3 v) { o << "[" << v.x << ", " << v.y << ", " << v.z << "]"; };
+    static const char* names[] = {"DIFF", "SPEC", "REFR"};
+    o << "{\"camera\": {\"origin\": "; v3(scene.camera.origin);
+    o << ", \"direction\": "; v3(scene.camera.direction);
+    o.precision(17);
+    o << ", \"fov\": " << scene.camera.fov;
+    o.precision(9);
+    o << ", \"push\": " << scene.camera.push << "}, \"spheres\": [";
+    for (size_t i = 0; i < scene.spheres.size(); ++i) {
+        const Sphere& s = scene.spheres[i];
+        o << (i ? ", " : "") << "{\"radius\": " << s.radius << ", \"center\": "; v3(s.center);
+        o << ", \"emission\": "; v3(s.material.emission);
+        o << ", \"color\": "; v3(s.material.color);
+        o << ", \"refl\": \"" << names[s.material.refl] << "\"}";
+    }
+    o << "]}";
+    return o.str();
+}
+
+}  // namespace spt_host

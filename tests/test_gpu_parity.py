@@ -183,3 +183,26 @@ def test_error_behaviour(pkg):
     with pytest.raises(pkg.SptError, match="outside image"):
         r.render_rows_device(t, 8, 8, 6, 4, 1)
     r.close()
+
+
+def test_cpp_cli_renders_same_ppm_as_oracle(pkg, oracle, tmp_path):
+    """The cpuRender-shaped C++ CLI (host/smallpt_cli.cpp): argv[1] = spp, writes the flipped P3 file."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(HERE), "optix-test-smallpt_amd", "host", "smallpt_mi355x")
+    out = tmp_path / "image.ppm"
+    r = subprocess.run([cli, "16", "--size", "64x48", "--seed", "3", "--out", str(out)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert b"Elapsed time:" in r.stderr
+    ref, _ = oracle.render(pkg.cornell9(), 64, 48, 4, seed=3, normalise=True)
+    exp = tmp_path / "ref.ppm"
+    pkg.write_ppm(exp, ref)
+    assert out.read_bytes() == exp.read_bytes()
+    # JSON scene path (config 5 route): same scene through a file
+    sc = pkg.random_spheres(64, 3)
+    p = tmp_path / "s.json"
+    p.write_text(pkg.spheres_to_json(sc))
+    r = subprocess.run([cli, "8", "--size", "40x30", "--scene", str(p), "--out", str(out)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    ref, _ = oracle.render(sc, 40, 30, 2, seed=0, normalise=True)
+    pkg.write_ppm(exp, ref)
+    assert out.read_bytes() == exp.read_bytes()

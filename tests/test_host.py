@@ -98,3 +98,46 @@ def test_gloo_world2_row_tiling_matches_single(pkg, oracle, tmp_path, h):
     got = np.load(out)
     ref, _ = oracle.render(pkg.cornell9(), w, h, samps, seed=seed, normalise=True)
     assert got.shape == (h, w, 3) and np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------ host C++ (the reference's language)
+CLI = os.path.join(ROOT, "optix-test-smallpt_amd", "host", "smallpt_mi355x")
+
+
+def _build_cli():
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "optix-test-smallpt_amd", "csrc"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.dirname(CLI), "-s"])
+
+
+def test_cpp_cornell_table_matches_python(pkg):
+    import subprocess
+    _build_cli()
+    raw = subprocess.check_output([CLI, "--parse-only"])
+    assert raw == pkg.cornell9().tobytes()
+
+
+def test_cpp_json_loader_matches_python(pkg, tmp_path):
+    import subprocess
+    _build_cli()
+    scene = pkg.random_spheres(1024, 1024)                       # config 5 goes through the JSON file
+    p = tmp_path / "scene.json"
+    p.write_text(pkg.spheres_to_json(scene))
+    raw = subprocess.check_output([CLI, "--scene", str(p), "--parse-only"])
+    assert raw == scene.tobytes()
+    # C++ writer -> C++ reader -> identical records; Python reads the C++ file too
+    q = tmp_path / "dump.json"
+    raw2 = subprocess.check_output([CLI, "--scene", str(p), "--dump-scene", str(q), "--parse-only"])
+    back, cam = pkg.spheres_from_json(q.read_text())
+    assert raw2 == scene.tobytes() and back.tobytes() == scene.tobytes() and cam["push"] == 140
+
+
+def test_cpp_json_loader_rejects_malformed(tmp_path):
+    import subprocess
+    _build_cli()
+    for bad in ('{"spheres": [{"radius": 1}]}', '{"spheres": [', '{"spheres": [{"radius":1,"center":[1,2],"emission":[0,0,0],"color":[0,0,0],"refl":"DIFF"}]}',
+                '{"spheres": [{"radius":1,"center":[1,2,3],"emission":[0,0,0],"color":[0,0,0],"refl":"GLOSSY"}]}'):
+        p = tmp_path / "bad.json"
+        p.write_text(bad)
+        r = subprocess.run([CLI, "--scene", str(p), "--parse-only"], capture_output=True)
+        assert r.returncode == 1 and b"scene JSON" in r.stderr

@@ -40,9 +40,10 @@ int main(int argc, char** argv)
 {
     long bad_sqrt = 0, bad_rcp = 0, bad_div = 0;
     int quick = argc > 1 && !strcmp(argv[1], "quick");
+    int rcp_only = argc > 1 && !strcmp(argv[1], "rcp-only");   /* full reciprocal enumeration only */
     uint32_t step = quick ? 7 : 1;
     /* (1) sqrt: x in [1,4) covers both exponent parities */
-    for (uint32_t u = f2u(1.0f); u < f2u(4.0f); u += step) {
+    for (uint32_t u = f2u(1.0f); u < f2u(4.0f) && !rcp_only; u += step) {
         float x = u2f(u), ref = sqrtf(x);
         for (int d = -DMAX; d <= DMAX; ++d) {
             float s0 = u2f(f2u(ref) + d);
@@ -63,7 +64,7 @@ int main(int argc, char** argv)
     bad_rcp = exc;
     /* (3) double division by small integers */
     uint64_t st = 88172645463325252ull;
-    long ndiv = quick ? 2000000 : 200000000;
+    long ndiv = rcp_only ? 0 : (quick ? 2000000 : 200000000);
     for (long i = 0; i < ndiv; ++i) {
         st ^= st << 13; st ^= st >> 7; st ^= st << 17;
         int w = 1 + (int)((st >> 40) % 16384);
