@@ -122,6 +122,11 @@ int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
  * out15[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters. */
 int  spt_diag(spt_ctx* ctx, unsigned long long* out15);
 
+/* Numerics self-test of the kernel's exact-math helpers (host arrays in/out, n elements):
+ * op 0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact, 4 (float)((double)x / w) by the FMA sequence,
+ * 5/6 sin/cos(2*pi*x) (D17), 7 rng_draw keyed by bits(x).  Used by tests/test_gpu_math.py. */
+int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32_t n, uint32_t w);
+
 /* Image output helpers kept from the reference: toInt (smallpt.cpp:52), flipY (:125-134) and the
  * ASCII P3 writer (:136-142).  rgb is w*h*3 floats, row 0 = bottom; the file gets the flipped image. */
 int  spt_to_int(float x);

@@ -43,6 +43,7 @@ SYMBOLS = {
     "spt_sync": (C.c_int, [_P, C.POINTER(SptStats)]),
     "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_diag": (C.c_int, [_P, C.POINTER(C.c_uint64 * 15)]),
+    "spt_selftest_math": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint32, C.c_uint32]),
     "spt_to_int": (C.c_int, [C.c_float]),
     "spt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
 }

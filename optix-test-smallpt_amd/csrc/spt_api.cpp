@@ -42,7 +42,7 @@ struct spt_ctx {
     float4* d_geom = nullptr;
     float4* d_mat = nullptr;
     uint32_t scene_cap = 0;
-    bool tiny_radius = false;      // some r*r < 2^-60: the hot-loop sqrt keeps its small-argument guard
+    bool needs_guard = false;      // r*r < 2^-60 or coordinates above 1e15: the hot-loop sqrt keeps its range guard
     // scratch
     float4* d_cells = nullptr;
     size_t cells_cap = 0;          // in float4
@@ -192,9 +192,14 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
     SPT_HIP(c, hipMemcpy(c->d_geom, geom.data(), sizeof(float4) * cap, hipMemcpyHostToDevice));
     SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
     c->n = n;
-    c->tiny_radius = false;
-    for (uint32_t i = 0; i < n; ++i)
-        if (!(s[i].radius * s[i].radius >= 0x1p-60f)) c->tiny_radius = true;
+    // The un-guarded sqrt fix-up in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
+    // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
+    c->needs_guard = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float big = std::fmax(std::fmax(std::fabs(s[i].center[0]), std::fabs(s[i].center[1])),
+                                    std::fmax(std::fabs(s[i].center[2]), std::fabs(s[i].radius)));
+        if (!(s[i].radius * s[i].radius >= 0x1p-60f) || !(big <= 1e15f)) c->needs_guard = true;
+    }
     return 0;
 }
 
@@ -266,10 +271,12 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
 
+    const float cam_big = std::fmax(std::fmax(std::fabs(cam->origin[0]), std::fabs(cam->origin[1])),
+                                    std::fmax(std::fabs(cam->origin[2]), std::fabs(cam->push)));
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
-    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, c->tiny_radius ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, st));
+    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, (c->needs_guard || !(cam_big <= 1e15f)) ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, st));
     SPT_HIP(c, hipEventRecord(c->ev_mid, st));
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
     SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
@@ -334,6 +341,25 @@ int spt_diag(spt_ctx* c, unsigned long long* out15)
 {
     if (!c || !out15) return 1;
     std::memcpy(out15, c->diag, sizeof c->diag);
+    return 0;
+}
+
+// Numerics self-test: runs device helper `op` (0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact,
+// 4 double division by w, 5/6 sin/cos(2*pi*x), 7 rng_draw(bits(x))) over n host floats.
+int spt_selftest_math(spt_ctx* c, int op, const float* in, float* out, uint32_t n, uint32_t w)
+{
+    if (!c) return 1;
+    if (!in || !out || !n || !w) return c->fail("spt_selftest_math: bad argument");
+    SPT_HIP(c, hipSetDevice(c->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * 4));
+    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 4));
+    hipError_t e = hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = spt_k_selftest(op, d_in, d_out, n, w, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return c->fail("spt_selftest_math: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -41,6 +41,22 @@ __device__ __forceinline__ float sqrt_fix(float x)
     s = ru > 0.0f ? su : s;
     return s;
 }
+// Same fix-up with the two selects done in integer arithmetic: s-1ulp + [rd > 0] + [ru > 0], where
+// [v > 0] = (0 - bits(v)) >> 31 for any v that is not -0 (rd, ru are exact-zero or non-zero residuals of
+// opposite-signed addends, so -0 cannot occur; x itself is never -0 at the call site).  Full-rate integer ops
+// instead of v_cmp/v_cndmask pairs.  Specified for x = 0, 2^-96 <= x < inf, x < 0 and NaN (x = +inf would give
+// FLT_MAX: the API routes scenes whose coordinates could overflow to the guarded build).
+__device__ __forceinline__ float sqrt_fix_int(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const uint32_t sb = __float_as_uint(s);
+    const float sd = __uint_as_float(sb - 1u);
+    const float su = __uint_as_float(sb + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x);
+    const float ru = __builtin_fmaf(-su, s, x);
+    const uint32_t up = ((0u - __float_as_uint(rd)) >> 31) + ((0u - __float_as_uint(ru)) >> 31);
+    return __uint_as_float(sb - 1u + up);
+}
 // General form: for 0 < x < 2^-96 the residuals would underflow, so those (practically never occurring)
 // inputs take the compiler's scaled sequence.  One integer compare covers the range test.
 __device__ __forceinline__ float sqrt_exact(float x)

@@ -19,7 +19,8 @@ namespace spt {
 
 constexpr int kBlock = 256;
 constexpr float kInf = 1e20f;   // maths.h:16
-constexpr float kEps = 1e-4f;   // scene.cpp:133
+constexpr uint32_t kEpsKeyBias = 0x38D1B717u + 1u;            // bits(1e-4f) + 1
+constexpr uint32_t kInfKey = 0x60AD78ECu - kEpsKeyBias;       // key of 1e20f (maths.h:16)
 
 // Per-thread LDS stack of pending transmitted children of the glass split (smallpt.cpp:252), <= 3 per
 // lane, laid out [entry][field][thread] so that every access is conflict-free.
@@ -120,8 +121,9 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
     uint32_t px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
     Path p{mk(0, 0, 0), mk(0, 0, 1), mk(0, 0, 0), 0u, 0u, 0u};
     f3 acc = mk(0, 0, 0);
-    float hit_t = 0.f;           // closest hit of the current bounce (kept while parked)
+    float hit_t = 0.f;           // closest hit of the current bounce
     uint32_t hit_inst = 0;
+    f3 pk_hx = mk(0, 0, 0), pk_n = mk(0, 0, 0), pk_nl = mk(0, 0, 0), pk_f = mk(0, 0, 0);   // parked glass hit
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform: this wave's private range of task ids
 
@@ -239,7 +241,11 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
         bool shade = false;
         if (alive && !parked) {
             ++nbounce;
-            float nearest = kInf;
+            // Selection on integer keys: for positive floats the bit pattern orders like the value, so with
+            // key(t) = bits(t) - (bits(eps) + 1) (mod 2^32) the test "t > eps && t < nearest" (scene.cpp:135-136,
+            // smallpt.cpp:61) is ONE unsigned compare key < nearest_key: t <= eps, negative t and NaN (det < 0) all
+            // wrap to keys above bits(1e20).  "t1 > eps ? t1 : t2" is min(key1, key2) because t2 >= t1.
+            uint32_t near_key = kInfKey;
             uint32_t inst = 0;
             float4 g = s_geom[0];
             for (uint32_t i = 0; i < P.n; ++i) {
@@ -247,30 +253,34 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 const f3 op = mk(g.x - p.o.x, g.y - p.o.y, g.z - p.o.z);               // :132
                 const float b = dot(op, p.d);                                          // :133
                 const float det = b * b - dot(op, op) + g.w;                           // :133 (g.w = r*r)
-                const float sd = GUARD ? sqrt_exact(det) : sqrt_fix(det);              // :134
-                const float t1 = b - sd, t2 = b + sd;                                  // :135
-                const float t = t1 > kEps ? t1 : t2;
-                if (t > kEps && t < nearest) { nearest = t; inst = i; }                // :135-136, smallpt.cpp:61
+                const float sd = GUARD ? sqrt_exact(det) : sqrt_fix_int(det);          // :134
+                const uint32_t key1 = __float_as_uint(b - sd) - kEpsKeyBias;           // :135
+                const uint32_t key2 = __float_as_uint(b + sd) - kEpsKeyBias;
+                const uint32_t key = key1 < key2 ? key1 : key2;
+                if (key < near_key) { near_key = key; inst = i; }                      // :135-136, smallpt.cpp:61
                 g = gn;
             }
+            const float nearest = near_key == kInfKey ? kInf : __uint_as_float(near_key + kEpsKeyBias);
             hit_t = nearest; hit_inst = inst;
             if (nearest == kInf) alive = false;                                        // :168 miss (D13)
             else shade = true;
         }
         SPT_STAMP(4)
         if (DIAG) { ++iters; lanes_d1 += __popcll(__ballot(shade || (!alive && hit_t == kInf))); lanes_d2 += __popcll(__ballot(shade)); }
-        // ---- phase D2: shadePaths for DIFF / SPEC hits; REFR hits are parked ----
+        // ---- phase D2: shadePaths (smallpt.cpp:170-223): common part for every hit, then DIFF / SPEC;
+        // REFR hits are parked after the common part (hit point, normal, emission, roulette) ----
         if (shade) {
             const float4 me = mats[3 * hit_inst + 0];         // emission.xyz, refl
+            const float4 gh = s_geom[hit_inst];
+            const float4 mc = mats[3 * hit_inst + 1];         // color.xyz, pmax
             const int refl = __float_as_int(me.w);
-            if (refl == 2) {
-                parked = true;
-            } else {
-                const float4 gh = s_geom[hit_inst];
-                const float4 mc = mats[3 * hit_inst + 1];     // color.xyz, pmax
-                f3 hx, n, nl, f;
-                bool cont = shade_common<GUARD>(p, hit_t, gh, me, mc, mats, hit_inst, k1, acc, hx, n, nl, f);
-                if (cont) {
+            f3 hx, n, nl, f;
+            bool cont = shade_common<GUARD>(p, hit_t, gh, me, mc, mats, hit_inst, k1, acc, hx, n, nl, f);
+            if (cont) {
+                if (refl == 2) {
+                    parked = true;
+                    pk_hx = hx; pk_n = n; pk_nl = nl; pk_f = f;
+                } else {
                     const f3 no = hx + nl * 0.02f;                                     // :172 (D3)
                     f3 nd;
                     if (refl == 0) {                                                   // DIFF :208-215
@@ -296,13 +306,13 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                     }
                     cont = extend(p, no, nd, f, nkill);
                 }
-                alive = cont;
             }
+            alive = cont;
         }
         SPT_STAMP(5)
         // ---- phase D3: glass (REFR, smallpt.cpp:225-263).  Executed for all parked lanes at once when enough
-        // of them wait (or nothing else is left to do), so the ~150-instruction block does not run for one
-        // or two lanes on every iteration. ----
+        // of them wait (or nothing else is left to do), so the block does not run for one or two lanes on
+        // every iteration. ----
         {
             const unsigned long long pm = __ballot(parked);
             const unsigned long long others = __ballot(alive && !parked);
@@ -310,51 +320,43 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 if (DIAG) { ++runs_d3; lanes_d3 += __popcll(pm); }
                 if (parked) {
                     parked = false;
-                    const float4 gh = s_geom[hit_inst];
-                    const float4 me = mats[3 * hit_inst + 0];
-                    const float4 mc = mats[3 * hit_inst + 1];
-                    f3 hx, n, nl, f;
-                    bool cont = shade_common<GUARD>(p, hit_t, gh, me, mc, mats, hit_inst, k1, acc, hx, n, nl, f);
-                    if (cont) {
-                        const f3 off = nl * 0.02f;                                     // :172 (D3)
-                        f3 no = hx + off, nf = f;
-                        f3 nd = p.d - n * 2.0f * dot(n, p.d);                          // :218 reflRay
-                        const bool into = dot(n, nl) > 0;                              // :225
-                        const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;            // :228
-                        const float ddn = dot(p.d, nl);                                // :229
-                        const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);           // :230
-                        if (!(cos2t < 0)) {                                            // else TIR :232-236
-                            const f3 tdir = normalize<true>(p.d * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t)))); // :238
-                            const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);            // :240-242
-                            const float c = 1 - (into ? -ddn : dot(tdir, n));          // :243
-                            const float c2 = c * c;                                    // :244
-                            const float Re = R0 + (1 - R0) * c2 * c2 * c;              // :245
-                            const float Tr = 1 - Re;                                   // :246
-                            const f3 xin = hx - off;                                   // D3
-                            if (p.depth <= 2) {                                        // :248 split (D6)
-                                // transmitted child -> LDS stack; reflected child continues (:251-252)
-                                const f3 tw = p.w * (f * Tr);
-                                if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
-                                    stack_at(sp, 0) = xin.x; stack_at(sp, 1) = xin.y; stack_at(sp, 2) = xin.z;
-                                    stack_at(sp, 3) = tdir.x; stack_at(sp, 4) = tdir.y; stack_at(sp, 5) = tdir.z;
-                                    stack_at(sp, 6) = tw.x; stack_at(sp, 7) = tw.y; stack_at(sp, 8) = tw.z;
-                                    stack_at(sp, 9) = __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16));
-                                    ++sp;
-                                }
-                                nf = f * Re;
-                            } else {
-                                const float Pr = 0.25f + 0.5f * Re;                    // :256
-                                if (rng_draw(p.rbase + kGolden, k1) < Pr) {
-                                    nf = f * Re * (1.0f / Pr);                         // :259
-                                } else {
-                                    nf = f * Tr * (1.0f / (1.f - Pr));                 // :263
-                                    no = xin; nd = tdir;
-                                }
+                    const f3 hx = pk_hx, n = pk_n, nl = pk_nl, f = pk_f;
+                    const f3 off = nl * 0.02f;                                         // :172 (D3)
+                    f3 no = hx + off, nf = f;
+                    f3 nd = p.d - n * 2.0f * dot(n, p.d);                              // :218 reflRay
+                    const bool into = dot(n, nl) > 0;                                  // :225
+                    const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;                // :228
+                    const float ddn = dot(p.d, nl);                                    // :229
+                    const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);               // :230
+                    if (!(cos2t < 0)) {                                                // else TIR :232-236
+                        const f3 tdir = normalize<true>(p.d * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t)))); // :238
+                        const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);                // :240-242
+                        const float c = 1 - (into ? -ddn : dot(tdir, n));              // :243
+                        const float c2 = c * c;                                        // :244
+                        const float Re = R0 + (1 - R0) * c2 * c2 * c;                  // :245
+                        const float Tr = 1 - Re;                                       // :246
+                        const f3 xin = hx - off;                                       // D3
+                        if (p.depth <= 2) {                                            // :248 split (D6)
+                            // transmitted child -> LDS stack; reflected child continues (:251-252)
+                            const f3 tw = p.w * (f * Tr);
+                            if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
+                                stack_at(sp, 0) = xin.x; stack_at(sp, 1) = xin.y; stack_at(sp, 2) = xin.z;
+                                stack_at(sp, 3) = tdir.x; stack_at(sp, 4) = tdir.y; stack_at(sp, 5) = tdir.z;
+                                stack_at(sp, 6) = tw.x; stack_at(sp, 7) = tw.y; stack_at(sp, 8) = tw.z;
+                                stack_at(sp, 9) = __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16));
+                                ++sp;
                             }
+                            nf = f * Re;
+                        } else {
+                            const float Pr = 0.25f + 0.5f * Re;                        // :256
+                            const bool pick_refl = rng_draw(p.rbase + kGolden, k1) < Pr;   // :257
+                            // :259 f*Re/P  or  :263 f*Tr/(1-P): operator/(float3,float) multiplies by 1.0f/x
+                            const float inv = rcp_exact(pick_refl ? Pr : 1.f - Pr);
+                            nf = f * (pick_refl ? Re : Tr) * inv;
+                            if (!pick_refl) { no = xin; nd = tdir; }
                         }
-                        cont = extend(p, no, nd, nf, nkill);
                     }
-                    alive = cont;
+                    alive = extend(p, no, nd, nf, nkill);
                 }
             }
         }
@@ -391,7 +393,38 @@ __global__ __launch_bounds__(kBlock) void finalize(const float4* __restrict__ ce
     out[3 * p + 0] = x; out[3 * p + 1] = y; out[3 * p + 2] = z;
 }
 
+// Applies one of the exact-math device helpers elementwise (numerics self-test, tests/test_gpu_math.py).
+__global__ void selftest_math(int op, const float* __restrict__ in, float* __restrict__ out, uint32_t n, double inv_w, uint32_t w)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float y;
+    switch (op) {
+    case 0: y = sqrt_fix(x); break;
+    case 1: y = sqrt_fix_int(x); break;
+    case 2: y = sqrt_exact(x); break;
+    case 3: y = rcp_exact(x); break;
+    case 4: {   // double division a / w by the Markstein sequence, a = (double)x
+        const double a = (double)x;
+        const double q0 = a * inv_w;
+        y = (float)__builtin_fma(__builtin_fma(-q0, (double)w, a), inv_w, q0);
+        break;
+    }
+    case 5: { float sn, cs; sincos2pi(x, sn, cs); y = sn; break; }
+    case 6: { float sn, cs; sincos2pi(x, sn, cs); y = cs; break; }
+    default: y = rng_draw(__float_as_uint(x), 0x9ABCDEF0u); break;
+    }
+    out[i] = y;
+}
+
 }  // namespace spt
+
+extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, uint32_t n, uint32_t w, hipStream_t stream)
+{
+    hipLaunchKernelGGL(spt::selftest_math, dim3((n + 255) / 256), dim3(256), 0, stream, op, d_in, d_out, n, 1.0 / (double)w, w);
+    return hipGetLastError();
+}
 
 // ---- launch wrappers used by spt_api.cpp ----
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds)

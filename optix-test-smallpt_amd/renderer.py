@@ -111,6 +111,14 @@ class Renderer:
         self._check(self._lib.spt_diag(self._h, C.byref(arr)))
         return [int(v) for v in arr]
 
+    def selftest_math(self, op, x, w=1024):
+        """Runs device helper `op` over the float32 array x (see spt_selftest_math)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(self._lib.spt_selftest_math(self._h, int(op), x.ctypes.data_as(C.c_void_p),
+                                                out.ctypes.data_as(C.c_void_p), x.size, int(w)))
+        return out
+
     def sync(self):
         st = SptStats()
         self._check(self._lib.spt_sync(self._h, C.byref(st)))

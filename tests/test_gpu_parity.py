@@ -34,6 +34,10 @@ def scenes(pkg):
         "rand16": pkg.random_spheres(16, 1),
         "rand300": pkg.random_spheres(300, 2),        # > 256 spheres: materials stay in HBM
         "rand1024": pkg.random_spheres(1024, 1024),   # config 5 scene
+        # scenes that select the guarded kernel build (spt_api.cpp needs_guard): r*r < 2^-60 / coordinates > 1e15
+        "tiny_radius": np.concatenate([pkg.cornell9(), pkg.make_spheres([(1e-12, (50, 40, 80), (0, 0, 0), (.5, .5, .5), pkg.DIFF)])]),
+        "huge_coord": np.concatenate([pkg.cornell9(), pkg.make_spheres([(1.0, (1e20, 0, 0), (0, 0, 0), (.5, .5, .5), pkg.DIFF),
+                                                                        (3e19, (0, 3.0000001e19, 0), (0, 0, 0), (.5, .5, .5), pkg.SPEC)])]),
         "single": pkg.make_spheres([(10, (50, 40.8, 81.6), (0, 0, 0), (.75, .25, .25), pkg.DIFF)]),
         "glass_only": pkg.make_spheres([(1e5, (50, 1e5, 81.6), (.2, .2, .2), (.75, .75, .75), pkg.DIFF),
                                         (16.5, (50, 30, 90), (0, 0, 0), (.999, .999, .999), pkg.REFR),
@@ -50,6 +54,8 @@ def scenes(pkg):
     ("rand300", 40, 30, 2, 8, False),
     ("rand1024", 48, 36, 2, 0, True),
     ("single", 32, 32, 4, 5, True),
+    ("tiny_radius", 40, 30, 3, 1, True),
+    ("huge_coord", 40, 30, 3, 1, True),
     ("glass_only", 48, 40, 8, 6, True),
     ("cornell9", 1, 1, 1, 0, True),
     ("cornell9", 3, 2, 300, 4, True),            # few tasks, many samples per task
