@@ -82,7 +82,7 @@ __device__ __forceinline__ bool extend(Path& p, f3 no, f3 nd, f3 nf, uint32_t& n
         tlast = now__;                                                         \
     }
 
-template <bool MAT_LDS, bool GUARD, bool DIAG>
+template <bool MAT_LDS, bool GUARD, bool DIAG, bool BIGN>
 __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
 {
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -201,10 +201,10 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 const float u2 = rng_draw(e.k0 + ((1u << 28) | 1u) * kGolden, e.k1);
                 // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt fix-up is exact here
                 const float r1 = 2 * u1;
-                const float q1 = sqrt_fix(r1 < 1 ? r1 : 2 - r1);
+                const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
                 const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
                 const float r2 = 2 * u2;
-                const float q2 = sqrt_fix(r2 < 1 ? r2 : 2 - r2);
+                const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
                 const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                 const uint32_t sx = cell & 1u, sy = cell >> 1;
                 // :331-332 in double as in the reference.  a / w is evaluated as q0 = a*y, q = fma(fma(-q0,w,a), y, q0)
@@ -247,18 +247,49 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
             // wrap to keys above bits(1e20).  "t1 > eps ? t1 : t2" is min(key1, key2) because t2 >= t1.
             uint32_t near_key = kInfKey;
             uint32_t inst = 0;
-            float4 g = s_geom[0];
-            for (uint32_t i = 0; i < P.n; ++i) {
-                const float4 gn = s_geom[i + 1 < P.n ? i + 1 : i];   // prefetch next sphere (wave-uniform LDS broadcast)
-                const f3 op = mk(g.x - p.o.x, g.y - p.o.y, g.z - p.o.z);               // :132
-                const float b = dot(op, p.d);                                          // :133
-                const float det = b * b - dot(op, op) + g.w;                           // :133 (g.w = r*r)
+            // one sphere test; branch-free (det < 0 -> NaN keys that never win)
+            auto test_sphere = [&](const float4 g, uint32_t i, float b, float det) {
                 const float sd = GUARD ? sqrt_exact(det) : sqrt_fix_int(det);          // :134
                 const uint32_t key1 = __float_as_uint(b - sd) - kEpsKeyBias;           // :135
                 const uint32_t key2 = __float_as_uint(b + sd) - kEpsKeyBias;
                 const uint32_t key = key1 < key2 ? key1 : key2;
                 if (key < near_key) { near_key = key; inst = i; }                      // :135-136, smallpt.cpp:61
-                g = gn;
+            };
+            auto b_det = [&](const float4 g, float& b, float& det) {
+                const f3 op = mk(g.x - p.o.x, g.y - p.o.y, g.z - p.o.z);               // :132
+                b = dot(op, p.d);                                                      // :133
+                det = b * b - dot(op, op) + g.w;                                       // :133 (g.w = r*r)
+            };
+            if (BIGN) {
+                // Large tables: most spheres are missed by every ray of the wave (det < 0 in all lanes,
+                // scene.cpp:134).  Groups of four spheres share one LDS wait and one wave-uniform test; the
+                // sqrt/selection part runs only for groups in which some lane has det >= 0.  Exact: a skipped
+                // sphere would have produced NaN keys in every lane.
+                uint32_t i = 0;
+                for (; i + 4 <= P.n; i += 4) {
+                    const float4 g0 = s_geom[i], g1 = s_geom[i + 1], g2 = s_geom[i + 2], g3 = s_geom[i + 3];
+                    float b0, b1, b2, b3, d0, d1, d2, d3;
+                    b_det(g0, b0, d0); b_det(g1, b1, d1); b_det(g2, b2, d2); b_det(g3, b3, d3);
+                    if (__ballot(d0 >= 0.0f || d1 >= 0.0f || d2 >= 0.0f || d3 >= 0.0f) != 0ull) {
+                        test_sphere(g0, i, b0, d0); test_sphere(g1, i + 1, b1, d1);
+                        test_sphere(g2, i + 2, b2, d2); test_sphere(g3, i + 3, b3, d3);
+                    }
+                }
+                for (; i < P.n; ++i) {
+                    const float4 g = s_geom[i];
+                    float b, det;
+                    b_det(g, b, det);
+                    test_sphere(g, i, b, det);
+                }
+            } else {
+                float4 g = s_geom[0];
+                for (uint32_t i = 0; i < P.n; ++i) {
+                    const float4 gn = s_geom[i + 1 < P.n ? i + 1 : i];   // prefetch next sphere (wave-uniform LDS broadcast)
+                    float b, det;
+                    b_det(g, b, det);
+                    test_sphere(g, i, b, det);
+                    g = gn;
+                }
             }
             const float nearest = near_key == kInfKey ? kInf : __uint_as_float(near_key + kEpsKeyBias);
             hit_t = nearest; hit_inst = inst;
@@ -286,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                     if (refl == 0) {                                                   // DIFF :208-215
                         const float u1 = rng_draw(p.rbase + kGolden, k1);
                         const float r2 = rng_draw(p.rbase + 2u * kGolden, k1);
-                        const float r2s = sqrt_fix(r2);                               // r2 in {0} U [2^-24, 1)
+                        const float r2s = sqrt_fix_int(r2);                               // r2 in {0} U [2^-24, 1)
                         float sn, cs;
                         sincos2pi(u1, sn, cs);                                          // D17
                         const f3 ww = nl;
@@ -298,9 +329,9 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                         const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
                         const float s2 = ay ? ww.x : ww.y;
                         const float qu = ww.z * ww.z + s2 * s2;       // dot(ur, ur) with the zero term dropped
-                        const f3 uu = ur * rcp_exact(sqrt_fix(qu));
+                        const f3 uu = ur * rcp_exact(sqrt_fix_int(qu));
                         const f3 vv = cross(ww, uu);
-                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix(1 - r2)); // :212
+                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix_int(1 - r2)); // :212
                     } else {
                         nd = p.d - n * 2.0f * dot(n, p.d);                             // SPEC :218-223
                     }
@@ -432,23 +463,28 @@ extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds)
     return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) + (size_t)spt::kStackEntries * spt::kStackFields * spt::kBlock * 4u;
 }
 
-template <bool M, bool G, bool D = false>
+template <bool M, bool G, bool D, bool B>
 static hipError_t launch_variant(const spt::KParams* P, uint32_t blocks, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<M, G, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<M, G, D, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((spt::megakernel<M, G, D>), dim3(blocks), dim3(spt::kBlock), lds, stream, *P);
+    hipLaunchKernelGGL((spt::megakernel<M, G, D, B>), dim3(blocks), dim3(spt::kBlock), lds, stream, *P);
     return hipGetLastError();
 }
 
 // guard != 0 selects the build whose hot-loop square roots keep the tiny-argument range check
 // (needed only for scenes with radius < 2^-30; see spt_api.cpp).
-extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, hipStream_t stream)
+// Build variants: mat_lds (materials staged in LDS, n <= 256), guard (range-guarded sqrt in the hot loop, only
+// for degenerate scenes), diag (instrumented), bign (wave-uniform det < 0 skip, pays off for large tables).
+extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, hipStream_t stream)
 {
     const size_t lds = spt_k_lds_bytes(P->n_pad, mat_lds);
-    if (diag) return mat_lds ? launch_variant<true, false, true>(P, blocks, lds, stream) : launch_variant<false, false, true>(P, blocks, lds, stream);
-    if (mat_lds) return guard ? launch_variant<true, true>(P, blocks, lds, stream) : launch_variant<true, false>(P, blocks, lds, stream);
-    return guard ? launch_variant<false, true>(P, blocks, lds, stream) : launch_variant<false, false>(P, blocks, lds, stream);
+    if (diag) return mat_lds ? launch_variant<true, false, true, false>(P, blocks, lds, stream) : launch_variant<false, false, true, true>(P, blocks, lds, stream);
+    if (mat_lds) {
+        if (bign) return guard ? launch_variant<true, true, false, true>(P, blocks, lds, stream) : launch_variant<true, false, false, true>(P, blocks, lds, stream);
+        return guard ? launch_variant<true, true, false, false>(P, blocks, lds, stream) : launch_variant<true, false, false, false>(P, blocks, lds, stream);
+    }
+    return guard ? launch_variant<false, true, false, true>(P, blocks, lds, stream) : launch_variant<false, false, false, true>(P, blocks, lds, stream);
 }
 
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream)
