@@ -58,14 +58,21 @@ typedef struct spt_sphere {
     uint32_t pad;
 } spt_sphere;
 
-/* smallpt camera (smallpt.cpp:277-279,331-333): d = cx*ax + cy*ay + dir; ray = (origin + d*push, normalize(d)) */
+/* Camera: d = cx*ax + cy*ay + dir; ray = (origin + d*push, normalize(d)).
+ * sampler = SPT_SAMPLER_SMALLPT: (ax, ay) from the 2x2-cell tent filter of cpuRender (smallpt.cpp:327-332,
+ *   evaluated in double like the reference); the smallpt camera of :277-279 has push = 140 (:333).
+ * sampler = SPT_SAMPLER_PINHOLE: (ax, ay) = clip-space position of Renderer::render's box-in-cell sample
+ *   (smallpt.cpp:745-760) fed to sampleRay (:626-641); cx, cy = columns 0, 1 of Camera::localToWorld,
+ *   dir = column 2 * nearPlaneDistance, origin = column 3, push = 0 (:607-641). */
 typedef struct spt_camera {
     float origin[3];
     float dir[3];
     float cx[3];
     float cy[3];
     float push;
+    uint32_t sampler;
 } spt_camera;
+enum { SPT_SAMPLER_SMALLPT = 0, SPT_SAMPLER_PINHOLE = 1 };
 
 typedef struct spt_stats {
     uint64_t samples;        /* camera paths traced (= rows*w*spp)                          */
@@ -95,6 +102,12 @@ int  spt_set_scene(spt_ctx* ctx, const spt_sphere* spheres, uint32_t n);
 
 /* Host-only helper: the camera constants of cpuRender for a w x h image (smallpt.cpp:277-279). */
 int  spt_camera_smallpt(uint32_t w, uint32_t h, spt_camera* out);
+
+/* Host-only helper: the pinhole Camera of the interactive driver, Camera{vx, vy, vz, org, nearPlaneDistance}
+ * (smallpt.cpp:607-624; main() uses vx=(1,0,0), vz=(0,0,-1), vy=normalize(cross(vx,vz)), org=(0,-1,0), near=1,
+ * :885-899).  Selects SPT_SAMPLER_PINHOLE. */
+int  spt_camera_pinhole(const float vx[3], const float vy[3], const float vz[3], const float org[3],
+                        float near_plane_distance, spt_camera* out);
 
 /* Renders the full w x h image and copies it to out_rgb (host, w*h*3 floats).  Blocking. */
 int  spt_render(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,

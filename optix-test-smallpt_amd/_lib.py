@@ -17,7 +17,7 @@ class SptSphere(C.Structure):
 
 class SptCamera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("cx", C.c_float * 3),
-                ("cy", C.c_float * 3), ("push", C.c_float)]
+                ("cy", C.c_float * 3), ("push", C.c_float), ("sampler", C.c_uint32)]
 
 
 class SptStats(C.Structure):
@@ -36,6 +36,7 @@ SYMBOLS = {
     "spt_device_count": (C.c_int, []),
     "spt_set_scene": (C.c_int, [_P, _P, C.c_uint32]),
     "spt_camera_smallpt": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(SptCamera)]),
+    "spt_camera_pinhole": (C.c_int, [C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float, C.POINTER(SptCamera)]),
     "spt_render": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                              C.c_uint32, _P, C.POINTER(SptStats)]),
     "spt_render_rows_device": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32,

@@ -216,6 +216,22 @@ int spt_camera_smallpt(uint32_t w, uint32_t h, spt_camera* out)
     out->cx[0] = cx.x; out->cx[1] = cx.y; out->cx[2] = cx.z;
     out->cy[0] = cy.x; out->cy[1] = cy.y; out->cy[2] = cy.z;
     out->push = 140.0f;
+    out->sampler = SPT_SAMPLER_SMALLPT;
+    return 0;
+}
+
+// Camera ctor smallpt.cpp:609-618 + sampleRay :635: direction = localToWorld * (clip.x, clip.y, near, 0)
+// = (vx*clip.x + vy*clip.y) + vz*near (+ org*0); vz*near is the same product for every sample.
+int spt_camera_pinhole(const float vx[3], const float vy[3], const float vz[3], const float org[3], float near_plane_distance, spt_camera* out)
+{
+    if (!vx || !vy || !vz || !org || !out) return 1;
+    for (int i = 0; i < 3; ++i) {
+        out->cx[i] = vx[i]; out->cy[i] = vy[i];
+        out->dir[i] = vz[i] * near_plane_distance;
+        out->origin[i] = org[i];
+    }
+    out->push = 0.0f;
+    out->sampler = SPT_SAMPLER_PINHOLE;
     return 0;
 }
 
@@ -247,6 +263,9 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     std::memcpy(P.cam_o, cam->origin, 12); std::memcpy(P.cam_d, cam->dir, 12);
     std::memcpy(P.cam_cx, cam->cx, 12); std::memcpy(P.cam_cy, cam->cy, 12);
     P.cam_push = cam->push;
+    if (cam->sampler > SPT_SAMPLER_PINHOLE) return c->fail("spt_render_rows_device: unknown camera sampler %u", cam->sampler);
+    P.sampler = cam->sampler;
+    P.inv_wf = 1.f / (float)w; P.inv_hf = 1.f / (float)h;   // pixelSize, smallpt.cpp:746
     P.w = w; P.h = h; P.row_begin = row_begin; P.row_count = row_count;
     P.inv_w = 1.0 / (double)w; P.inv_h = 1.0 / (double)h;
     P.samps = samps; P.ntasks = (uint32_t)ntasks;

@@ -11,6 +11,8 @@ struct KParams {
     // camera (smallpt.cpp:277-279,333)
     float cam_o[3], cam_d[3], cam_cx[3], cam_cy[3];
     float cam_push;
+    uint32_t sampler;        // 0 smallpt tent filter (cpuRender), 1 box-in-cell + pinhole (Renderer::render)
+    float inv_wf, inv_hf;    // 1.f/w, 1.f/h (pixelSize, smallpt.cpp:746)
     // image / band
     uint32_t w, h, row_begin, row_count;
     double inv_w, inv_h;     // RN(1/w), RN(1/h) for the exact double division of smallpt.cpp:331-332

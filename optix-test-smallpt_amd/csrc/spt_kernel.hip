@@ -199,22 +199,34 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 e.k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
                 const float u1 = rng_draw(e.k0 + ((1u << 28) | 0u) * kGolden, e.k1);
                 const float u2 = rng_draw(e.k0 + ((1u << 28) | 1u) * kGolden, e.k1);
-                // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt fix-up is exact here
-                const float r1 = 2 * u1;
-                const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
-                const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
-                const float r2 = 2 * u2;
-                const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
-                const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                 const uint32_t sx = cell & 1u, sy = cell >> 1;
-                // :331-332 in double as in the reference.  a / w is evaluated as q0 = a*y, q = fma(fma(-q0,w,a), y, q0)
-                // with y = RN(1/w): the correctly rounded quotient (Markstein; checked in tools/verify_exact_math.c).
-                const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
-                const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
-                const double qx0 = tx * P.inv_w, qy0 = ty * P.inv_h;
-                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)P.w, tx), P.inv_w, qx0);
-                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)P.h, ty), P.inv_h, qy0);
-                const float ax = (float)(qx - .5), ay = (float)(qy - .5);
+                float ax, ay;
+                if (P.sampler == 0u) {
+                    // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt fix-up is exact here
+                    const float r1 = 2 * u1;
+                    const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
+                    const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
+                    const float r2 = 2 * u2;
+                    const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
+                    const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
+                    // :331-332 in double as in the reference.  a / w is evaluated as q0 = a*y, q = fma(fma(-q0,w,a), y, q0)
+                    // with y = RN(1/w): the correctly rounded quotient (Markstein; checked in tools/verify_exact_math.c).
+                    const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
+                    const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
+                    const double qx0 = tx * P.inv_w, qy0 = ty * P.inv_h;
+                    const double qx = __builtin_fma(__builtin_fma(-qx0, (double)P.w, tx), P.inv_w, qx0);
+                    const double qy = __builtin_fma(__builtin_fma(-qy0, (double)P.h, ty), P.inv_h, qy0);
+                    ax = (float)(qx - .5); ay = (float)(qy - .5);
+                } else {
+                    // Renderer::render sampling, smallpt.cpp:745-760 + sampleRay :626-633 (all binary32):
+                    // jittered = ((groupColumn, groupRow) + rand) * 0.5; box filter 0.5 * (2 r - 1); raster position
+                    // (col + 0.5f) + that; * pixelSize; clip = 2 n - 1.
+                    const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;      // :750
+                    const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);              // :753-758
+                    const float nx = (((float)px + 0.5f) + fx) * P.inv_wf;                       // :628-631
+                    const float ny = (((float)py + 0.5f) + fy) * P.inv_hf;
+                    ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;                                    // :633
+                }
                 e.dd = cam_cx * ax + cam_cy * ay + cam_d;
                 e.inv = rcp_exact(sqrt_exact(dot(e.dd, e.dd)));
                 if (rcount == 0) ra = e; else rb = e;

@@ -67,6 +67,7 @@ spt_camera make_camera(const CameraDesc& c, uint32_t w, uint32_t h)
     cam.cx[0] = cx.x; cam.cx[1] = cx.y; cam.cx[2] = cx.z;
     cam.cy[0] = cy.x; cam.cy[1] = cy.y; cam.cy[2] = cy.z;
     cam.push = c.push;
+    cam.sampler = SPT_SAMPLER_SMALLPT;
     return cam;
 }
 

@@ -28,6 +28,23 @@ def smallpt_camera(w, h):
     return cam
 
 
+def pinhole_camera(vx=(1, 0, 0), vy=None, vz=(0, 0, -1), org=(0, -1, 0), near=1.0):
+    """Camera{vx, vy, vz, org, nearPlaneDistance} of the interactive driver (smallpt.cpp:607-624); the defaults
+    are main()'s values (:885-888,899), vy = normalize(cross(vx, vz))."""
+    lib = load_library()
+    f = np.float32
+    if vy is None:
+        a, b = np.asarray(vx, dtype=f), np.asarray(vz, dtype=f)
+        c = np.array([f(a[1] * b[2]) - f(a[2] * b[1]), f(a[2] * b[0]) - f(a[0] * b[2]), f(a[0] * b[1]) - f(a[1] * b[0])], dtype=f)
+        q = f(f(c[0] * c[0]) + f(c[1] * c[1])) + f(c[2] * c[2])
+        vy = c * (f(1) / np.sqrt(f(q)))
+    cam = SptCamera()
+    v3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    if lib.spt_camera_pinhole(v3(vx), v3(vy), v3(vz), v3(org), float(near), C.byref(cam)):
+        raise SptError("spt_camera_pinhole failed")
+    return cam
+
+
 def _stats_dict(st):
     return {"samples": int(st.samples), "bounces": int(st.bounces), "max_depth_kills": int(st.max_depth_kills),
             "kernel_ms": float(st.kernel_ms), "finalize_ms": float(st.finalize_ms), "total_ms": float(st.total_ms),

@@ -217,21 +217,48 @@ void orc_camera_smallpt(uint32_t w, uint32_t h, orc_camera* cam)
     f3 cy = scl(normalize(cross(cx, dir)), (float).5135);     /* :279 */
     st(cam->origin, o); st(cam->dir, dir); st(cam->cx, cx); st(cam->cy, cy);
     cam->push = 140.0f;                                       /* :333 */
+    cam->sampler = 0;
+}
+
+/* Camera ctor smallpt.cpp:609-618: localToWorld columns (vx, vy, vz, org).  sampleRay (:635) multiplies it by
+ * (clip.x, clip.y, near, 0): optix Matrix4x4 * float4 = ((m0*x + m1*y) + m2*z) + m3*w per row, so
+ * direction = (vx*clip.x + vy*clip.y) + vz*near, the trailing + org*0 adds a signed zero. */
+void orc_camera_pinhole(const float vx[3], const float vy[3], const float vz[3], const float org[3], float near_plane, orc_camera* cam)
+{
+    st(cam->cx, ld(vx)); st(cam->cy, ld(vy));
+    st(cam->dir, scl(ld(vz), near_plane));
+    st(cam->origin, ld(org));
+    cam->push = 0.0f;
+    cam->sampler = 1;
 }
 
 /* smallpt.cpp:327-333 (D8 tent filter, D10 camera).  jitterSize = 2 (:285). */
 static inline void camera_ray(const orc_camera* cam, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
                               uint32_t sx, uint32_t sy, float u1, float u2, f3* o, f3* d)
 {
-    const float r1 = 2 * u1;                                              /* :327 */
-    const float dx = r1 < 1 ? sqrtf(r1) - 1 : 1 - sqrtf(2 - r1);          /* :328 */
-    const float r2 = 2 * u2;                                              /* :329 */
-    const float dy = r2 < 1 ? sqrtf(r2) - 1 : 1 - sqrtf(2 - r2);          /* :330 */
-    /* :331-332: size_t + double literal => the bracket is evaluated in double, then converted to
-     * float by operator*(float3, float). */
-    const double ax = (((double)sx + .5 + (double)dx) / 2.0 + (double)px) / (double)(int)w - .5;
-    const double ay = (((double)sy + .5 + (double)dy) / 2.0 + (double)py) / (double)(int)h - .5;
-    const f3 dd = add(add(scl(ld(cam->cx), (float)ax), scl(ld(cam->cy), (float)ay)), ld(cam->dir));
+    float fax, fay;
+    if (cam->sampler == 0) {
+        const float r1 = 2 * u1;                                              /* :327 */
+        const float dx = r1 < 1 ? sqrtf(r1) - 1 : 1 - sqrtf(2 - r1);          /* :328 */
+        const float r2 = 2 * u2;                                              /* :329 */
+        const float dy = r2 < 1 ? sqrtf(r2) - 1 : 1 - sqrtf(2 - r2);          /* :330 */
+        /* :331-332: size_t + double literal => the bracket is evaluated in double, then converted to
+         * float by operator*(float3, float). */
+        const double ax = (((double)sx + .5 + (double)dx) / 2.0 + (double)px) / (double)(int)w - .5;
+        const double ay = (((double)sy + .5 + (double)dy) / 2.0 + (double)py) / (double)(int)h - .5;
+        fax = (float)ax; fay = (float)ay;
+    } else {
+        /* Renderer::render :745-760 */
+        const float cellx = 1.f / 2, celly = 1.f / 2;                         /* :745 jitterCellSize */
+        const float pixw = 1.f / (float)w, pixh = 1.f / (float)h;             /* :746 pixelSize */
+        const float jx = ((float)sx + u1) * cellx, jy = ((float)sy + u2) * celly; /* :750 */
+        const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);       /* :753-758 box filter in [-0.5, 0.5] */
+        /* sampleRay :626-633 */
+        const float rx = ((float)px + 0.5f) + fx, ry = ((float)py + 0.5f) + fy; /* :628-630 */
+        const float nx = rx * pixw, ny = ry * pixh;                           /* :631 */
+        fax = 2.f * nx - 1.f; fay = 2.f * ny - 1.f;                           /* :633 */
+    }
+    const f3 dd = add(add(scl(ld(cam->cx), fax), scl(ld(cam->cy), fay)), ld(cam->dir));   /* :331-332 / :635 */
     *o = add(ld(cam->origin), scl(dd, cam->push));                         /* :333 */
     *d = normalize(dd);
 }

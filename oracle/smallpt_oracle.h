@@ -41,6 +41,8 @@ typedef struct {
     float cx[3];         /* horizontal image-plane vector          */
     float cy[3];         /* vertical image-plane vector            */
     float push;          /* 140: ray origin = cam.o + d*push       */
+    uint32_t sampler;    /* 0: cpuRender tent filter (smallpt.cpp:327-332); 1: Renderer::render box-in-cell +
+                            sampleRay pinhole (smallpt.cpp:745-760,626-641) */
 } orc_camera;
 
 typedef struct {
@@ -75,6 +77,8 @@ float orc_rng_uniform(uint32_t k0, uint32_t k1, uint32_t ctr);
 void  orc_sincos2pi(float u, float* s, float* c);
 /* camera of smallpt.cpp:277-279 for a w x h image */
 void  orc_camera_smallpt(uint32_t w, uint32_t h, orc_camera* cam);
+/* Camera{vx,vy,vz,org,near} of smallpt.cpp:607-624 in the d = cx*ax + cy*ay + dir form */
+void  orc_camera_pinhole(const float vx[3], const float vy[3], const float vz[3], const float org[3], float near_plane, orc_camera* cam);
 /* smallpt.cpp:327-333: camera ray of sample (px,py,sx,sy) given the two uniforms */
 void  orc_camera_ray(const orc_camera* cam, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
                      uint32_t sx, uint32_t sy, float u1, float u2, float o[3], float d[3]);

@@ -15,7 +15,7 @@ SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("emission", "
 
 class OrcCamera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("cx", C.c_float * 3),
-                ("cy", C.c_float * 3), ("push", C.c_float)]
+                ("cy", C.c_float * 3), ("push", C.c_float), ("sampler", C.c_uint32)]
 
 
 class OrcStats(C.Structure):

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_layouts(pkg):
     assert C.sizeof(pkg.SptSphere) == 48 == pkg.SPHERE_DTYPE.itemsize
-    assert C.sizeof(pkg.SptCamera) == 52
+    assert C.sizeof(pkg.SptCamera) == 56
     assert pkg.SptSphere.radius.offset == 12 and pkg.SptSphere.refl.offset == 40
     hdr = open(HEADER).read()
     assert "SPT_MAX_DEPTH      4096u" in hdr
@@ -41,6 +41,16 @@ def test_camera_helper_matches_oracle(pkg, oracle):
         a = pkg.smallpt_camera(w, h)
         b = oracle.camera_smallpt(w, h)
         assert bytes(a) == bytes(b)
+
+
+def test_pinhole_camera_helper_matches_oracle(pkg, oracle):
+    """Camera{vx, vy, vz, org, near} of the interactive driver (smallpt.cpp:607-624,885-899)."""
+    a = pkg.pinhole_camera()
+    b = oracle.OrcCamera()
+    vy = [float(v) for v in a.cy]
+    oracle.lib().orc_camera_pinhole(oracle.f3(1, 0, 0), oracle.f3(*vy), oracle.f3(0, 0, -1), oracle.f3(0, -1, 0), C.c_float(1.0), C.byref(b))
+    assert bytes(a) == bytes(b) and a.sampler == 1 and a.push == 0.0
+    assert list(a.cy) == [0.0, 1.0, 0.0] and list(a.dir) == [0.0, 0.0, -1.0]     # vy = normalize(cross(vx, vz))
 
 
 def test_to_int_matches_oracle(pkg, oracle):

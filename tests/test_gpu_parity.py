@@ -82,6 +82,33 @@ def test_golden_fixtures(pkg, renderer, name):
     assert np.array_equal(img, g["image"]) and st["bounces"] == int(g["bounces"])
 
 
+def pinhole_scene(pkg):
+    """Spheres in front of the interactive driver's pinhole camera (org (0,-1,0), looking down -z)."""
+    return pkg.make_spheres([
+        (1e4, (0, -1e4 - 2, -6), (0, 0, 0), (.7, .7, .7), pkg.DIFF),        # floor
+        (30.0, (0, 40, -6), (3, 3, 3), (0, 0, 0), pkg.DIFF),               # light
+        (1.0, (-2.2, -1, -6), (0, 0, 0), (.75, .25, .25), pkg.DIFF),
+        (1.0, (0, -1, -7), (0, 0, 0), (.999, .999, .999), pkg.SPEC),
+        (1.0, (2.2, -1, -5.5), (0, 0, 0), (.999, .999, .999), pkg.REFR),
+    ])
+
+
+@pytest.mark.parametrize("w,h,samps,seed", [(64, 36, 2, 0), (1280 // 8, 720 // 8, 1, 5), (33, 21, 3, 2)])
+def test_renderer_render_mode_pinhole_box_in_cell(pkg, renderer, oracle, w, h, samps, seed):
+    """The Renderer::render-shaped entry (smallpt.cpp:692-814): pinhole Camera + sampleRay, box-in-cell sampling,
+    un-normalised sum, seed = frame counter."""
+    sc = pinhole_scene(pkg)
+    cam = pkg.pinhole_camera()
+    renderer.set_scene(sc)
+    img, st = renderer.render(w, h, samps, seed=seed, normalise=False, camera=cam)
+    ref, rst = oracle.render(sc, w, h, samps, seed=seed, normalise=False, camera=cam)
+    check(img, st, ref, rst)
+    assert img.max() > 0
+    # progressive accumulation as the viewer thread does it (smallpt.cpp:924-936): frames differ, their mean converges
+    img2, _ = renderer.render(w, h, samps, seed=seed + 1, normalise=False, camera=cam)
+    assert not np.array_equal(img, img2)
+
+
 def test_empty_scene_is_black(pkg, renderer):
     renderer.set_scene(pkg.make_spheres([]))
     img, st = renderer.render(16, 8, 2)

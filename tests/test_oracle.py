@@ -71,7 +71,7 @@ def test_kat_tri_intersect(oracle):
 def test_struct_sizes_match_reference(oracle):
     # scene.h: float3 12 B, Ray 24 B; Material {float3,float3,Refl_t} 28 B -> carried inside the 48-B sphere POD
     assert oracle.SPHERE_DTYPE.itemsize == 48
-    assert C.sizeof(oracle.OrcCamera) == 52
+    assert C.sizeof(oracle.OrcCamera) == 56
     assert KATS["sizeof"]["Material"] == 28 and KATS["sizeof"]["Ray"] == 24
 
 
@@ -235,6 +235,28 @@ def test_camera_ray_double_promotion(oracle):
         o, d = oracle.f3(0, 0, 0), oracle.f3(0, 0, 0)
         L.orc_camera_ray(C.byref(cam), w, h, px, py, sx, sy, float(u1), float(u2), o, d)
         assert [f32(v) for v in o] == list(eo) and [f32(v) for v in d] == list(ed)
+
+
+def test_camera_ray_pinhole_box_in_cell(oracle):
+    """Renderer::render sampling (smallpt.cpp:745-760) + sampleRay (:626-641), all binary32, restated in numpy."""
+    L = oracle.lib()
+    w, h = 1280, 720                                   # main(), smallpt.cpp:844-845
+    cam = oracle.OrcCamera()
+    L.orc_camera_pinhole(oracle.f3(1, 0, 0), oracle.f3(0, 1, 0), oracle.f3(0, 0, -1), oracle.f3(0, -1, 0), C.c_float(1.0), C.byref(cam))
+    rs = np.random.RandomState(7)
+    for _ in range(300):
+        px, py = int(rs.randint(0, w)), int(rs.randint(0, h))
+        sx, sy = int(rs.randint(0, 2)), int(rs.randint(0, 2))
+        u1, u2 = (f32(v) * f32(2.0**-24) for v in rs.randint(0, 1 << 24, 2))
+        jx, jy = f32(f32(f32(sx) + u1) * f32(.5)), f32(f32(f32(sy) + u2) * f32(.5))
+        fx, fy = f32(f32(.5) * f32(f32(f32(2) * jx) - f32(1))), f32(f32(.5) * f32(f32(f32(2) * jy) - f32(1)))
+        nx = f32(f32(f32(f32(px) + f32(.5)) + fx) * f32(f32(1) / f32(w)))
+        ny = f32(f32(f32(f32(py) + f32(.5)) + fy) * f32(f32(1) / f32(h)))
+        cx_, cy_ = f32(f32(f32(2) * nx) - f32(1)), f32(f32(f32(2) * ny) - f32(1))
+        dd = np.array([cx_, cy_, f32(-1.0)], dtype=f32)      # vx*cx + vy*cy + vz*near with the axis-aligned basis
+        o, d = oracle.f3(0, 0, 0), oracle.f3(0, 0, 0)
+        L.orc_camera_ray(C.byref(cam), w, h, px, py, sx, sy, float(u1), float(u2), o, d)
+        assert [f32(v) for v in d] == list(_normalize(dd)) and list(o) == [0.0, -1.0, 0.0]
 
 
 def test_to_int(oracle):
