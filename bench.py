@@ -75,22 +75,33 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SPT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices and the
+    # gather goes through host memory); the driver's runs use the default, nccl = RCCL over xGMI.
+    backend = os.environ.get("SPT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     h = H_PER_GPU * world
     begin, count = row_band(h, world, rank)
     samps = args.samps
-    r = pkg.Renderer(local_rank)
+    r = pkg.Renderer(dev_index)
     r.set_scene(pkg.cornell9())
     band = torch.empty((count, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         r.render_rows_device(band, W, h, begin, count, samps, seed=0, normalise=True, stream=stream)
+        if world > 1 and backend != "nccl":
+            st = r.sync()
+            full = gather_rows(band.cpu(), W, h)
+            return full, st
         full = gather_rows(band, W, h) if world > 1 else band
         st = r.sync()
         return full, st
@@ -112,7 +123,8 @@ def main():
         bounces += st["bounces"]; samples += st["samples"]
     fence()
     elapsed = time.perf_counter() - t0
-    tot = torch.tensor([elapsed, float(samples), float(bounces), sum(kms) / len(kms)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(samples), float(bounces), sum(kms) / len(kms)], dtype=torch.float64,
+                       device=dev if backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)

@@ -82,8 +82,8 @@ __device__ __forceinline__ bool extend(Path& p, f3 no, f3 nd, f3 nf, uint32_t& n
         tlast = now__;                                                         \
     }
 
-template <bool MAT_LDS, bool GUARD, bool DIAG, bool BIGN>
-__global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
+template <bool MAT_LDS, bool GUARD, bool DIAG, bool BIGN, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
 {
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
     float* s_stack = reinterpret_cast<float*>(lds + P.n_pad + (MAT_LDS ? 3 * P.n_pad : 0));
 
     const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < P.n; i += kBlock) {
+    for (uint32_t i = tid; i < P.n; i += BLOCK) {
         s_geom[i] = P.geom[i];
         if (MAT_LDS) {
             s_mat[3 * i + 0] = P.mat[3 * i + 0];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform: this wave's private range of task ids
 
-    auto stack_at = [&](uint32_t e, int f) -> float& { return s_stack[(e * kStackFields + f) * kBlock + tid]; };
+    auto stack_at = [&](uint32_t e, int f) -> float& { return s_stack[(e * kStackFields + f) * BLOCK + tid]; };
 
     for (;;) {
         SPT_STAMP(7)
@@ -277,14 +277,30 @@ __global__ __launch_bounds__(kBlock) void megakernel(const KParams P)
                 // scene.cpp:134).  Groups of four spheres share one LDS wait and one wave-uniform test; the
                 // sqrt/selection part runs only for groups in which some lane has det >= 0.  Exact: a skipped
                 // sphere would have produced NaN keys in every lane.
-                uint32_t i = 0;
-                for (; i + 4 <= P.n; i += 4) {
-                    const float4 g0 = s_geom[i], g1 = s_geom[i + 1], g2 = s_geom[i + 2], g3 = s_geom[i + 3];
+                // Two register sets of four spheres are processed alternately; each is refilled (LDS, wave-uniform
+                // broadcast reads) right after use, so its latency hides behind the other set's arithmetic.
+                auto group = [&](uint32_t i, const float4 g0, const float4 g1, const float4 g2, const float4 g3) {
                     float b0, b1, b2, b3, d0, d1, d2, d3;
                     b_det(g0, b0, d0); b_det(g1, b1, d1); b_det(g2, b2, d2); b_det(g3, b3, d3);
                     if (__ballot(d0 >= 0.0f || d1 >= 0.0f || d2 >= 0.0f || d3 >= 0.0f) != 0ull) {
-                        test_sphere(g0, i, b0, d0); test_sphere(g1, i + 1, b1, d1);
-                        test_sphere(g2, i + 2, b2, d2); test_sphere(g3, i + 3, b3, d3);
+                        if (__ballot(d0 >= 0.0f) != 0ull) test_sphere(g0, i, b0, d0);
+                        if (__ballot(d1 >= 0.0f) != 0ull) test_sphere(g1, i + 1, b1, d1);
+                        if (__ballot(d2 >= 0.0f) != 0ull) test_sphere(g2, i + 2, b2, d2);
+                        if (__ballot(d3 >= 0.0f) != 0ull) test_sphere(g3, i + 3, b3, d3);
+                    }
+                };
+                uint32_t i = 0;
+                const uint32_t n8 = P.n & ~7u;
+                if (n8) {
+                    auto ldg = [&](uint32_t k) -> float4 { return s_geom[k]; };
+                    float4 a0 = ldg(0), a1 = ldg(1), a2 = ldg(2), a3 = ldg(3);
+                    float4 c0 = ldg(4), c1 = ldg(5), c2 = ldg(6), c3 = ldg(7);
+                    for (; i < n8; i += 8) {
+                        const uint32_t j = i + 8 < n8 ? i + 8 : i;      // next pair of groups (clamped: re-reads the last)
+                        group(i, a0, a1, a2, a3);
+                        a0 = ldg(j); a1 = ldg(j + 1); a2 = ldg(j + 2); a3 = ldg(j + 3);
+                        group(i + 4, c0, c1, c2, c3);
+                        c0 = ldg(j + 4); c1 = ldg(j + 5); c2 = ldg(j + 6); c3 = ldg(j + 7);
                     }
                 }
                 for (; i < P.n; ++i) {
@@ -470,33 +486,40 @@ extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, ui
 }
 
 // ---- launch wrappers used by spt_api.cpp ----
-extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds)
-{
-    return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) + (size_t)spt::kStackEntries * spt::kStackFields * spt::kBlock * 4u;
-}
 
-template <bool M, bool G, bool D, bool B>
+template <bool M, bool G, bool D, bool B, int BLOCK>
 static hipError_t launch_variant(const spt::KParams* P, uint32_t blocks, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<M, G, D, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::megakernel<M, G, D, B, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((spt::megakernel<M, G, D, B>), dim3(blocks), dim3(spt::kBlock), lds, stream, *P);
+    hipLaunchKernelGGL((spt::megakernel<M, G, D, B, BLOCK>), dim3(blocks), dim3(BLOCK), lds, stream, *P);
     return hipGetLastError();
 }
 
-// guard != 0 selects the build whose hot-loop square roots keep the tiny-argument range check
-// (needed only for scenes with radius < 2^-30; see spt_api.cpp).
 // Build variants: mat_lds (materials staged in LDS, n <= 256), guard (range-guarded sqrt in the hot loop, only
-// for degenerate scenes), diag (instrumented), bign (wave-uniform det < 0 skip, pays off for large tables).
+// for degenerate scenes), diag (instrumented), bign (grouped wave-uniform det < 0 skip, large tables).
+// Large tables (materials in HBM) run 512-thread workgroups so that one LDS copy of the geometry serves 8 waves.
+static int g_big_block = 512;   // tuning knob (spt_set_tuning variant bit 9 selects 256)
+extern "C" void spt_k_set_big_block(int threads) { g_big_block = threads == 256 ? 256 : 512; }
+extern "C" int spt_k_block_threads_for(int mat_lds) { return mat_lds ? spt::kBlock : g_big_block; }
+
+extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds)
+{
+    const size_t block = (size_t)spt_k_block_threads_for(mat_lds);
+    return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) + (size_t)spt::kStackEntries * spt::kStackFields * block * 4u;
+}
+
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, hipStream_t stream)
 {
     const size_t lds = spt_k_lds_bytes(P->n_pad, mat_lds);
-    if (diag) return mat_lds ? launch_variant<true, false, true, false>(P, blocks, lds, stream) : launch_variant<false, false, true, true>(P, blocks, lds, stream);
+    constexpr int B0 = spt::kBlock;
+    if (diag) return mat_lds ? launch_variant<true, false, true, false, B0>(P, blocks, lds, stream) : (g_big_block == 256 ? launch_variant<false, false, true, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, true, true, 512>(P, blocks, lds, stream));
     if (mat_lds) {
-        if (bign) return guard ? launch_variant<true, true, false, true>(P, blocks, lds, stream) : launch_variant<true, false, false, true>(P, blocks, lds, stream);
-        return guard ? launch_variant<true, true, false, false>(P, blocks, lds, stream) : launch_variant<true, false, false, false>(P, blocks, lds, stream);
+        if (bign) return guard ? launch_variant<true, true, false, true, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, true, B0>(P, blocks, lds, stream);
+        return guard ? launch_variant<true, true, false, false, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, false, B0>(P, blocks, lds, stream);
     }
-    return guard ? launch_variant<false, true, false, true>(P, blocks, lds, stream) : launch_variant<false, false, false, true>(P, blocks, lds, stream);
+    if (g_big_block == 256) return guard ? launch_variant<false, true, false, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 256>(P, blocks, lds, stream);
+    return guard ? launch_variant<false, true, false, true, 512>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 512>(P, blocks, lds, stream);
 }
 
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream)
