@@ -50,7 +50,7 @@ def cpu_baseline(pkg, budget_s=15.0):
     dt = time.perf_counter() - t0
     return {"value": round(st["samples"] / dt / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
             "sample": f"Cornell-9 {W}x{H_PER_GPU} at {4 * samps} spp ({st['samples']} samples, {dt:.1f} s wall, "
-                      f"OpenMP dynamic rows, oracle/smallpt_oracle.c)",
+                      f"OpenMP dynamic 16-pixel chunks, oracle/smallpt_oracle.c)",
             "bounces_per_sample": round(st["bounces"] / st["samples"], 4)}
 
 

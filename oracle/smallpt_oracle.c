@@ -414,7 +414,7 @@ int orc_num_threads(void)
 #endif
 }
 
-/* cpuRender smallpt.cpp:269-361: per row (:317), per pixel/cell/sample in the order of
+/* cpuRender smallpt.cpp:269-361: per pixel/cell/sample in the order of
  * foreachSampleInRow (:294-314).  D9 accumulation order: every emission event is added straight
  * into its cell accumulator in (sample-major, DFS) order; the pixel is ((c0+c1)+c2)+c3. */
 int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
@@ -428,16 +428,21 @@ int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
     if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return 1;
     uint64_t tot_b = 0, tot_k = 0;
     const uint32_t spp = 4 * samps;                                   /* :286 */
+    /* The reference parallelises over rows (:317); here the unit is a chunk of 16 consecutive pixels so that a
+     * band of a few rows still uses every core.  Pixels are independent, so the image does not depend on it. */
+    const int64_t npix = (int64_t)row_count * w;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : tot_b, tot_k)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+ : tot_b, tot_k)
 #endif
-    for (int64_t r = 0; r < (int64_t)row_count; ++r) {               /* :317 */
+    for (int64_t pi = 0; pi < npix; ++pi) {
         trace_ctx tc;
         tc.sph = spheres; tc.n = n; tc.zero_cut = !(flags & ORC_FLAG_NO_ZERO_WEIGHT_CUT);
         tc.bounces = 0; tc.depth_kills = 0;
-        const uint32_t py = row_begin + (uint32_t)r;
-        for (uint32_t px = 0; px < w; ++px) {                         /* :296 */
+        const uint32_t r = (uint32_t)(pi / w);
+        const uint32_t px = (uint32_t)(pi - (int64_t)r * w);                    /* :296 */
+        const uint32_t py = row_begin + r;                                      /* :317 */
+        {
             const uint32_t pixel_idx = py * w + px;                   /* :298 */
             f3 cell[4];
             for (uint32_t sy = 0; sy < 2; ++sy)                       /* :299 */

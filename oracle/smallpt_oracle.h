@@ -88,7 +88,7 @@ int   orc_to_int(float x);
 /* --- the render (cpuRender :269-361 restated) ---
  * Renders rows [row_begin, row_begin+row_count) of a w x h image into out (row_count*w*3 floats,
  * row 0 of the band first; row index 0 = bottom of the image, D14).
- * threads<=0: all cores (OpenMP, dynamic 1-row scheduling).  Returns 0 on success. */
+ * threads<=0: all cores (OpenMP, dynamic scheduling of 16-pixel chunks).  Returns 0 on success. */
 int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
                uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
                uint32_t samps_per_cell, uint64_t seed, uint32_t flags, int threads,

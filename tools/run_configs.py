@@ -1,0 +1,103 @@
+"""Runs the BASELINE.json configurations that fit one MI355X and fills BASELINE.md section 4's table:
+end-to-end and kernel Msamples/s, bounces/sample, algorithmic flops/sample, fraction of the FP32 rooflines,
+HBM GB/s of the store kernel, and rel-L2 / bit-exactness vs the CPU oracle (full image where the oracle finishes in
+about a minute on this host, a set of full rows otherwise).  Writes gpurun_out/configs.json and .md."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import optix_test_smallpt_amd as pkg  # noqa: E402
+import oracle_binding as orc  # noqa: E402
+from optix_test_smallpt_amd.distributed import row_band  # noqa: E402
+
+PEAK, PEAK_HALF = 157.3, 78.6
+quick = "--quick" in sys.argv
+
+
+def rel_l2(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / np.sqrt((b.astype(np.float64) ** 2).sum()))
+
+
+def run(name, scene, w, h, samps, band=None, oracle_rows=None, reps=2):
+    r = pkg.Renderer(0)
+    r.set_scene(scene)
+    n = len(scene)
+    begin, count = band if band else (0, h)
+    out = torch.empty((count, w, 3), dtype=torch.float32, device="cuda:0")
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.render_rows_device(out, w, h, begin, count, samps, seed=0, normalise=True)
+        st = r.sync()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if best is None or wall < best[0]:
+            best = (wall, st)
+    wall, st = best
+    img = out.cpu().numpy()
+    bbar = st["bounces"] / st["samples"]
+    fl = 45 + bbar * (17 * n + 100)
+    tf = st["samples"] * fl / (st["kernel_ms"] * 1e-3) / 1e12
+    rows = oracle_rows if oracle_rows is not None else list(range(count))
+    t0 = time.perf_counter()
+    worst, exact, checked = 0.0, True, 0
+    if len(rows) == count:
+        ref, _ = orc.render(scene, w, h, samps, seed=0, normalise=True, row_begin=begin, row_count=count)
+        worst = rel_l2(img, ref)
+        exact = bool(np.array_equal(img, ref))
+        checked = count
+    else:
+        for rr in rows:
+            ref, _ = orc.render(scene, w, h, samps, seed=0, normalise=True, row_begin=begin + rr, row_count=1)
+            worst = max(worst, rel_l2(img[rr:rr + 1], ref))
+            exact &= bool(np.array_equal(img[rr:rr + 1], ref))
+            checked += 1
+    row = {"config": name, "spheres": n, "image": f"{w}x{h}", "rows": f"{begin}..{begin + count - 1}", "spp": 4 * samps,
+           "samples": st["samples"], "wall_ms": round(wall * 1e3, 2), "kernel_ms": round(st["kernel_ms"], 2),
+           "finalize_ms": round(st["finalize_ms"], 4),
+           "msamples_s_end_to_end": round(st["samples"] / wall / 1e6, 1),
+           "msamples_s_kernel": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
+           "bounces_per_sample": round(bbar, 4), "flops_per_sample": round(fl, 1), "tflops": round(tf, 2),
+           "pct_of_157.3": round(100 * tf / PEAK, 2), "pct_of_78.6": round(100 * tf / PEAK_HALF, 2),
+           "store_GBps": round(count * w * 76 / (st["finalize_ms"] * 1e-3) / 1e9, 0),
+           "oracle_rows_checked": checked, "rel_l2_vs_cpu": worst, "bit_exact": exact,
+           "oracle_s": round(time.perf_counter() - t0, 1)}
+    print(json.dumps(row), flush=True)
+    r.close()
+    return row
+
+
+def main():
+    rows = []
+    cornell = pkg.cornell9()
+    rows.append(run("2: Cornell-9 1024x768 1024spp", cornell, 1024, 768, 256 if not quick else 8,
+                    oracle_rows=None if not quick else [0, 400]))
+    rows.append(run("3: Cornell-9 1024x768 16384spp", cornell, 1024, 768, 4096 if not quick else 16,
+                    oracle_rows=[0, 383, 767] if not quick else [5]))
+    b, c = row_band(4096, 8, 3)
+    rows.append(run("4: Cornell-9 4096x4096 4096spp, rank 3 of 8 (512 rows)", cornell, 4096, 4096, 1024 if not quick else 2,
+                    band=(b, c), oracle_rows=[0, 511] if not quick else [7]))
+    rows.append(run("5: 1024 spheres 1024x768 1024spp", pkg.random_spheres(1024, 1024), 1024, 768, 256 if not quick else 2,
+                    oracle_rows=[100, 600] if not quick else [3], reps=1))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
+    with open(os.path.join(ROOT, "gpurun_out", "configs.md"), "w") as f:
+        f.write("| Config | GPUs | Msamples/s (end-to-end) | Msamples/s (kernel) | B̄ bounces/sample | flops/sample | "
+                "% of 157.3 TF | % of 78.6 TF | HBM GB/s on store | rel-L2 vs CPU (rows checked) | bit-exact |\n"
+                "|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for r_ in rows:
+            f.write(f"| {r_['config']} | 1 | {r_['msamples_s_end_to_end']} | {r_['msamples_s_kernel']} | {r_['bounces_per_sample']} | "
+                    f"{r_['flops_per_sample']} | {r_['pct_of_157.3']} | {r_['pct_of_78.6']} | {r_['store_GBps']:.0f} | "
+                    f"{r_['rel_l2_vs_cpu']:.1e} ({r_['oracle_rows_checked']}) | {r_['bit_exact']} |\n")
+    print(open(os.path.join(ROOT, "gpurun_out", "configs.md")).read())
+
+
+if __name__ == "__main__":
+    main()
