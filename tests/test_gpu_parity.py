@@ -32,7 +32,10 @@ def scenes(pkg):
         "cornell9": pkg.cornell9(),
         "cornell9_e12": pkg.cornell9(12.0),
         "rand16": pkg.random_spheres(16, 1),
+        "rand25": pkg.random_spheres(25, 4),          # > 24 spheres: grouped wave-uniform skip, materials in LDS
+        "rand257": pkg.random_spheres(257, 6),        # first size with materials in HBM + 512-thread workgroups
         "rand300": pkg.random_spheres(300, 2),        # > 256 spheres: materials stay in HBM
+        "rand4096": pkg.random_spheres(4096, 9),      # SPT_MAX_SPHERES: 64 KB of LDS geometry
         "rand1024": pkg.random_spheres(1024, 1024),   # config 5 scene
         # scenes that select the guarded kernel build (spt_api.cpp needs_guard): r*r < 2^-60 / coordinates > 1e15
         "tiny_radius": np.concatenate([pkg.cornell9(), pkg.make_spheres([(1e-12, (50, 40, 80), (0, 0, 0), (.5, .5, .5), pkg.DIFF)])]),
@@ -51,7 +54,10 @@ def scenes(pkg):
     ("cornell9", 37, 53, 5, 123456789012345, False),
     ("cornell9_e12", 50, 20, 3, 2, True),
     ("rand16", 80, 60, 4, 1, True),
+    ("rand25", 40, 30, 2, 3, True),
+    ("rand257", 36, 28, 2, 4, True),
     ("rand300", 40, 30, 2, 8, False),
+    ("rand4096", 20, 14, 1, 1, True),
     ("rand1024", 48, 36, 2, 0, True),
     ("single", 32, 32, 4, 5, True),
     ("tiny_radius", 40, 30, 3, 1, True),
