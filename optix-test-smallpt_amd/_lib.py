@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmallpt_mi355x.so")
+# SPT_LIB overrides the library path (A/B of compiler-flag variants of the same source; tools/build_variants.sh)
+LIB_PATH = os.environ.get("SPT_LIB") or os.path.join(_HERE, "csrc", "libsmallpt_mi355x.so")
 
 
 class SptSphere(C.Structure):
