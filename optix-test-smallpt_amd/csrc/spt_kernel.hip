@@ -310,14 +310,21 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                     test_sphere(g, i, b, det);
                 }
             } else {
-                float4 g = s_geom[0];
-                for (uint32_t i = 0; i < P.n; ++i) {
-                    const float4 gn = s_geom[i + 1 < P.n ? i + 1 : i];   // prefetch next sphere (wave-uniform LDS broadcast)
-                    float b, det;
-                    b_det(g, b, det);
-                    test_sphere(g, i, b, det);
-                    g = gn;
+                // Small tables (n <= 24): fully unrolled with wave-uniform early exit, so that the LDS offsets and
+                // the sphere indices are immediates (no per-sphere SGPR->VGPR moves, which issue at half rate).
+#define SPT_SPH(i)                                                   \
+                if (P.n <= (i)) goto spheres_done;                                  \
+                {                                                                   \
+                    const float4 g = s_geom[(i)];                                   \
+                    float b, det;                                                   \
+                    b_det(g, b, det);                                               \
+                    test_sphere(g, (i), b, det);                                    \
                 }
+                SPT_SPH(0) SPT_SPH(1) SPT_SPH(2) SPT_SPH(3) SPT_SPH(4) SPT_SPH(5) SPT_SPH(6) SPT_SPH(7)
+                SPT_SPH(8) SPT_SPH(9) SPT_SPH(10) SPT_SPH(11) SPT_SPH(12) SPT_SPH(13) SPT_SPH(14) SPT_SPH(15)
+                SPT_SPH(16) SPT_SPH(17) SPT_SPH(18) SPT_SPH(19) SPT_SPH(20) SPT_SPH(21) SPT_SPH(22) SPT_SPH(23)
+#undef SPT_SPH
+            spheres_done:;
             }
             const float nearest = near_key == kInfKey ? kInf : __uint_as_float(near_key + kEpsKeyBias);
             hit_t = nearest; hit_inst = inst;
