@@ -61,6 +61,13 @@ __global__ __launch_bounds__(256) void k(float* out, float a0, float b0, unsigne
                 if (OP == 41) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x[i]) : "v"(u0));
                 if (OP == 42) asm volatile("v_rsq_f32 %0, %0" : "+v"(x[i]));
                 if (OP == 43) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(b) : );
+                if (OP == 44) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(z[i & 3]) : "v"(y[i]), "v"(u0) : "s20", "s21");
+                if (OP == 45) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x[i]));
+                if (OP == 46) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 47) asm volatile("v_min_u32 %0, %0, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 48) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 49) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(y[i]), "v"(u0) : "vcc");
+                if (OP == 50) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x[i]) : "v"(b));
                 if (OP == 8) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(y[i]) : "v"(u0));
                 if (OP == 9) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[i]), "v"(b) : "vcc");
                 if (OP == 10) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(y[i]) : "v"(u0));
@@ -127,6 +134,8 @@ int main()
         run<32>("v_cvt_f32_i32", w, d); run<33>("v_sub_u32", w, d); run<34>("v_cmp+2 v_nop (x3)", w, d); run<35>("v_nop", w, d);
         run<36>("v_bfi_b32", w, d); run<37>("v_xad_u32", w, d); run<38>("v_alignbit_b32", w, d); run<39>("v_mul_u32_u24", w, d);
         run<40>("v_mul_hi_u32", w, d); run<41>("v_ldexp_f32", w, d); run<42>("v_rsq_f32", w, d);
+        run<44>("v_mad_u64_u32", w, d); run<45>("v_cvt_i32_f32", w, d); run<46>("v_add3_u32", w, d); run<47>("v_min_u32", w, d);
+        run<48>("v_and_or_b32", w, d); run<49>("v_cmp_lt_u32", w, d); run<50>("v_fmac_f32", w, d);
         printf("\n");
     }
     return 0;
