@@ -444,19 +444,35 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
     }
 }
 
-// D9: pixel = ((c0 + c1) + c2) + c3, optional * (1/spp) (smallpt.cpp:358-361).  One lane per pixel,
-// 64 B contiguous cell reads per lane, 12 B per pixel written; w*rows*12 bytes of HBM stores.
+// D9: pixel = ((c0 + c1) + c2) + c3, optional * (1/spp) (smallpt.cpp:358-361).  One lane per pixel: 64 B of
+// contiguous cell sums in, 12 B out.  The packed float3 rows are written with coalesced 16-byte stores: the
+// workgroup's 256 pixels (3 KB) are transposed through LDS and stored as 192 float4 (ALIGNED16 build; the
+// scalar build serves output pointers that are not 16-byte aligned).  HBM-bound: 76 B per pixel.
+template <bool ALIGNED16>
 __global__ __launch_bounds__(kBlock) void finalize(const float4* __restrict__ cells, float* __restrict__ out,
                                                    uint32_t npix, float scale, int normalise)
 {
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= npix) return;
-    const float4 c0 = cells[4 * p + 0], c1 = cells[4 * p + 1], c2 = cells[4 * p + 2], c3 = cells[4 * p + 3];
-    float x = ((c0.x + c1.x) + c2.x) + c3.x;
-    float y = ((c0.y + c1.y) + c2.y) + c3.y;
-    float z = ((c0.z + c1.z) + c2.z) + c3.z;
-    if (normalise) { x *= scale; y *= scale; z *= scale; }
-    out[3 * p + 0] = x; out[3 * p + 1] = y; out[3 * p + 2] = z;
+    __shared__ float4 s_px[(kBlock * 3) / 4];
+    const uint32_t base = blockIdx.x * kBlock;
+    const uint32_t p = base + threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (p < npix) {
+        const float4 c0 = cells[4 * p + 0], c1 = cells[4 * p + 1], c2 = cells[4 * p + 2], c3 = cells[4 * p + 3];
+        x = ((c0.x + c1.x) + c2.x) + c3.x;
+        y = ((c0.y + c1.y) + c2.y) + c3.y;
+        z = ((c0.z + c1.z) + c2.z) + c3.z;
+        if (normalise) { x *= scale; y *= scale; z *= scale; }
+    }
+    const bool full = base + kBlock <= npix;       // workgroup-uniform
+    if (ALIGNED16 && full) {
+        float* s = reinterpret_cast<float*>(s_px);
+        s[3 * threadIdx.x + 0] = x; s[3 * threadIdx.x + 1] = y; s[3 * threadIdx.x + 2] = z;
+        __syncthreads();
+        if (threadIdx.x < (kBlock * 3) / 4)
+            reinterpret_cast<float4*>(out + (size_t)base * 3)[threadIdx.x] = s_px[threadIdx.x];
+    } else if (p < npix) {
+        out[3 * (size_t)p + 0] = x; out[3 * (size_t)p + 1] = y; out[3 * (size_t)p + 2] = z;
+    }
 }
 
 // Applies one of the exact-math device helpers elementwise (numerics self-test, tests/test_gpu_math.py).
@@ -532,7 +548,10 @@ extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int m
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream)
 {
     const uint32_t blocks = (npix + spt::kBlock - 1) / spt::kBlock;
-    hipLaunchKernelGGL(spt::finalize, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise);
+    if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)     // 256 pixels * 12 B = 3 KB per workgroup keeps every block base aligned
+        hipLaunchKernelGGL(spt::finalize<true>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise);
+    else
+        hipLaunchKernelGGL(spt::finalize<false>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise);
     return hipGetLastError();
 }
 

@@ -173,6 +173,20 @@ def test_row_bands_on_device_match_full_image(pkg, renderer):
         assert np.array_equal(np.concatenate(parts), full)
 
 
+def test_unaligned_output_pointer(pkg, renderer):
+    """The store kernel has a 16-byte-aligned fast path (LDS transpose + float4 stores) and a scalar path."""
+    import torch
+    w, h, samps = 70, 9, 2
+    renderer.set_scene(pkg.cornell9())
+    full, _ = renderer.render(w, h, samps, seed=4, normalise=True)
+    buf = torch.empty(h * w * 3 + 1, dtype=torch.float32, device="cuda:0")
+    view = buf[1:]                                   # data_ptr is 4 mod 16
+    assert view.data_ptr() % 16 != 0
+    renderer.render_rows_device(view, w, h, 0, h, samps, seed=4, normalise=True)
+    renderer.sync()
+    assert np.array_equal(view.cpu().numpy().reshape(h, w, 3), full)
+
+
 def test_large_image_global_pixel_index(pkg, renderer, oracle):
     """Config 4 geometry: a 4096x4096 image row-tiled over 8 ranks; check a few rows of rank 5's band."""
     w = h = 4096
