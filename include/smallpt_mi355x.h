@@ -124,6 +124,11 @@ int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uin
                             uint32_t samps_per_cell, uint64_t seed, uint32_t flags,
                             void* d_out_rgb, void* hip_stream);
 
+/* Progressive accumulation of the viewer's render thread (smallpt.cpp:924-937), device-resident:
+ * d_accum[i] = clear ? d_frame[i] : d_accum[i] + d_frame[i] for n floats (both 16-byte aligned, on this device);
+ * enqueued on hip_stream (NULL = the context's stream).  Display weight = 1/(frames*spp) (smallpt.cpp:957). */
+int  spt_accumulate_device(spt_ctx* ctx, void* d_accum, const void* d_frame, uint64_t n, int clear, void* hip_stream);
+
 /* Waits for the last launch of this context and fills stats (may be NULL). */
 int  spt_sync(spt_ctx* ctx, spt_stats* stats);
 

@@ -4,11 +4,11 @@ include/smallpt_mi355x.h (csrc/); this package is the thin host-side mirror of t
 scene structs and render entry points.  Import name: ``optix_test_smallpt_amd`` (see the shim at
 the repository root)."""
 from ._lib import LIB_PATH, SYMBOLS, SptCamera, SptSphere, SptStats, load_library  # noqa: F401
-from .renderer import (FLAG_NORMALISE, Renderer, SptError, pinhole_camera, smallpt_camera, to_int,  # noqa: F401
-                       write_ppm)
+from .renderer import (FLAG_NORMALISE, ProgressiveRenderer, Renderer, SptError, pinhole_camera,  # noqa: F401
+                       smallpt_camera, to_int, write_ppm)
 from .scene import (DIFF, REFR, SPEC, SPHERE_DTYPE, cornell9, make_spheres, random_spheres,  # noqa: F401
                     spheres_from_json, spheres_to_json)
 
-__all__ = ["Renderer", "SptError", "smallpt_camera", "pinhole_camera", "cornell9", "random_spheres", "make_spheres",
+__all__ = ["Renderer", "ProgressiveRenderer", "SptError", "smallpt_camera", "pinhole_camera", "cornell9", "random_spheres", "make_spheres",
            "spheres_from_json", "spheres_to_json", "SPHERE_DTYPE", "DIFF", "SPEC", "REFR",
            "load_library", "to_int", "write_ppm", "FLAG_NORMALISE"]

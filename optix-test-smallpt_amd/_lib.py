@@ -42,6 +42,7 @@ SYMBOLS = {
                              C.c_uint32, _P, C.POINTER(SptStats)]),
     "spt_render_rows_device": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
+    "spt_accumulate_device": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _P]),
     "spt_sync": (C.c_int, [_P, C.POINTER(SptStats)]),
     "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_diag": (C.c_int, [_P, C.POINTER(C.c_uint64 * 15)]),

@@ -356,6 +356,20 @@ int spt_render(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h, uint32
     return 0;
 }
 
+// accumBuffer += outImage of the render thread (smallpt.cpp:924-937), device-resident; clear != 0 restarts the
+// accumulation (needClearBuffer, :931-933).  Both pointers: n floats on this context's device, 16-byte aligned.
+int spt_accumulate_device(spt_ctx* c, void* d_accum, const void* d_frame, uint64_t n, int clear, void* hip_stream)
+{
+    if (!c) return 1;
+    if (!d_accum || !d_frame || !n) return c->fail("spt_accumulate_device: bad argument");
+    if ((reinterpret_cast<uintptr_t>(d_accum) | reinterpret_cast<uintptr_t>(d_frame)) & 15u)
+        return c->fail("spt_accumulate_device: buffers must be 16-byte aligned");
+    SPT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    SPT_HIP(c, spt_k_accumulate(static_cast<float*>(d_accum), static_cast<const float*>(d_frame), (size_t)n, clear, st));
+    return 0;
+}
+
 // Diagnostic (tuning variant bit 8): per-phase wave-time sums [0..7], iterations, lane counts of the last launch.
 int spt_diag(spt_ctx* c, unsigned long long* out15)
 {

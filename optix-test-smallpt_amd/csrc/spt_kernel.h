@@ -40,3 +40,4 @@ extern "C" int spt_k_block_threads(void);
 extern "C" int spt_k_block_threads_for(int mat_lds);
 extern "C" void spt_k_set_big_block(int threads);
 extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, uint32_t n, uint32_t w, hipStream_t stream);
+extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream);

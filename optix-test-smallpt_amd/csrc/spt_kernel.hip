@@ -475,6 +475,24 @@ __global__ __launch_bounds__(kBlock) void finalize(const float4* __restrict__ ce
     }
 }
 
+// Progressive accumulation of the viewer's render thread (smallpt.cpp:924-937): accum = clear ? frame : accum + frame,
+// float4-vectorised grid-stride loop; n4 float4 elements plus a scalar tail.
+__global__ __launch_bounds__(kBlock) void accumulate(float* __restrict__ accum, const float* __restrict__ frame, size_t n, int clear)
+{
+    const size_t n4 = n / 4;
+    float4* a4 = reinterpret_cast<float4*>(accum);
+    const float4* f4 = reinterpret_cast<const float4*>(frame);
+    for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        const float4 f = f4[i];
+        if (clear) { a4[i] = f; continue; }
+        float4 a = a4[i];
+        a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
+        a4[i] = a;
+    }
+    for (size_t i = n4 * 4 + blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        accum[i] = clear ? frame[i] : accum[i] + frame[i];
+}
+
 // Applies one of the exact-math device helpers elementwise (numerics self-test, tests/test_gpu_math.py).
 __global__ void selftest_math(int op, const float* __restrict__ in, float* __restrict__ out, uint32_t n, double inv_w, uint32_t w)
 {
@@ -501,6 +519,15 @@ __global__ void selftest_math(int op, const float* __restrict__ in, float* __res
 }
 
 }  // namespace spt
+
+extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream)
+{
+    size_t blocks = (n / 4 + spt::kBlock - 1) / spt::kBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(spt::accumulate, dim3((unsigned)blocks), dim3(spt::kBlock), 0, stream, accum, frame, n, clear);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, uint32_t n, uint32_t w, hipStream_t stream)
 {

@@ -142,6 +142,42 @@ class Renderer:
         return _stats_dict(st)
 
 
+class ProgressiveRenderer:
+    """The viewer's render-thread loop (smallpt.cpp:895-942) with the accumulation buffer resident in HBM:
+    every ``step()`` renders one frame with seed = frame counter (:893,922,926) as an un-normalised sum
+    (Renderer::render convention), adds it to the accumulation tensor (:935) and returns the display weight
+    1/(frames*spp) of :957.  ``update_camera`` mirrors the "update_camera" request (:911-916): new camera,
+    buffer cleared on the next frame, counter restarted."""
+
+    def __init__(self, renderer, w, h, samps_per_cell, camera=None):
+        import torch
+        self.r, self.w, self.h, self.samps = renderer, w, h, samps_per_cell
+        self.camera = camera if camera is not None else pinhole_camera()
+        dev = torch.device("cuda", renderer.device_id)
+        self.accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        self.frame = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+        self.frames = 0
+        self._clear = True
+
+    def update_camera(self, camera):
+        self.camera = camera
+        self._clear = True
+
+    def step(self):
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+        seed = 0 if self._clear else self.frames       # sampleCount restarts at 1 after a clear (:938-939)
+        self.r.render_rows_device(self.frame, self.w, self.h, 0, self.h, self.samps, seed=seed, normalise=False,
+                                  camera=self.camera, stream=stream)
+        self.r._check(self.r._lib.spt_accumulate_device(self.r._h, C.c_void_p(self.accum.data_ptr()),
+                                                        C.c_void_p(self.frame.data_ptr()), self.accum.numel(),
+                                                        1 if self._clear else 0, C.c_void_p(stream)))
+        self.frames = 1 if self._clear else self.frames + 1
+        self._clear = False
+        self.r.sync()
+        return 1.0 / (self.frames * 4 * self.samps)
+
+
 def to_int(x):
     """toInt, smallpt.cpp:52."""
     return load_library().spt_to_int(float(x))

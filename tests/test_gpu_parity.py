@@ -115,6 +115,28 @@ def test_renderer_render_mode_pinhole_box_in_cell(pkg, renderer, oracle, w, h, s
     assert not np.array_equal(img, img2)
 
 
+def test_progressive_accumulation_matches_frame_sum(pkg, renderer, oracle):
+    """Render-thread loop (smallpt.cpp:895-942): frames with seed = frame counter accumulated in HBM; a camera
+    update clears the buffer and restarts the counter."""
+    w, h, samps = 48, 27, 1
+    sc = pinhole_scene(pkg)
+    renderer.set_scene(sc)
+    cam = pkg.pinhole_camera()
+    prog = pkg.ProgressiveRenderer(renderer, w, h, samps, camera=cam)
+    acc = np.zeros((h, w, 3), dtype=np.float32)
+    for frame in range(3):
+        weight = prog.step()
+        ref, _ = oracle.render(sc, w, h, samps, seed=frame, normalise=False, camera=cam)
+        acc = acc + ref                                            # accumBuffer += outImage, :935
+        assert weight == 1.0 / ((frame + 1) * 4 * samps)
+        assert np.array_equal(prog.accum.cpu().numpy(), acc)
+    cam2 = pkg.pinhole_camera(org=(0, -0.99, 0))                   # key UP moves org.y by 0.01, :968-971
+    prog.update_camera(cam2)
+    prog.step()
+    ref, _ = oracle.render(sc, w, h, samps, seed=0, normalise=False, camera=cam2)
+    assert prog.frames == 1 and np.array_equal(prog.accum.cpu().numpy(), ref)
+
+
 def test_empty_scene_is_black(pkg, renderer):
     renderer.set_scene(pkg.make_spheres([]))
     img, st = renderer.render(16, 8, 2)
