@@ -278,7 +278,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
 
     // launch geometry: a persistent grid that fills the chip; the task queue makes any size correct
     const int mat_lds = (c->n <= 256) ? 1 : 0;
-    spt_k_set_big_block((c->variant & 0x200u) ? 256 : 512);
+    spt_k_set_big_block((c->variant & 0x200u) ? 512 : 256);   // A/B on the box: 256 is faster once the LDS reads are prefetched
     const size_t lds = spt_k_lds_bytes(P.n_pad, mat_lds);
     const int threads = spt_k_block_threads_for(mat_lds);
     uint32_t per_cu = c->blocks_per_cu;

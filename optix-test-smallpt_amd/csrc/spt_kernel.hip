@@ -292,16 +292,37 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                 uint32_t i = 0;
                 const uint32_t n8 = P.n & ~7u;
                 if (n8) {
-                    auto ldg = [&](uint32_t k) -> float4 { return s_geom[k]; };
-                    float4 a0 = ldg(0), a1 = ldg(1), a2 = ldg(2), a3 = ldg(3);
-                    float4 c0 = ldg(4), c1 = ldg(5), c2 = ldg(6), c3 = ldg(7);
+                    // Hand-issued LDS reads (hipcc splits prefetched float4 records into 32 ds_read_b32 with an
+                    // address move each).  LDS operations complete in order, so "lgkmcnt(4)" = everything except the
+                    // four youngest reads has landed: the set being consumed is ready while the other set's refill
+                    // is still in flight.  No other LDS/SMEM operation is issued inside this loop.
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f a0, a1, a2, a3, c0, c1, c2, c3;
+                    const uint32_t geom_base = (uint32_t)(uintptr_t)s_geom;      // LDS byte address of the table
+#define SPT_LDS4(r0, r1, r2, r3, byteaddr)                                                                         \
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"                           \
+                                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"                      \
+                                 : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(byteaddr) : "memory")
+#define SPT_WAIT4(r0, r1, r2, r3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory")
+#define SPT_F4(v) make_float4((v).x, (v).y, (v).z, (v).w)
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): nothing older in flight
+                    SPT_LDS4(a0, a1, a2, a3, geom_base);
+                    SPT_LDS4(c0, c1, c2, c3, geom_base + 64u);
                     for (; i < n8; i += 8) {
                         const uint32_t j = i + 8 < n8 ? i + 8 : i;      // next pair of groups (clamped: re-reads the last)
-                        group(i, a0, a1, a2, a3);
-                        a0 = ldg(j); a1 = ldg(j + 1); a2 = ldg(j + 2); a3 = ldg(j + 3);
-                        group(i + 4, c0, c1, c2, c3);
-                        c0 = ldg(j + 4); c1 = ldg(j + 5); c2 = ldg(j + 6); c3 = ldg(j + 7);
+                        SPT_WAIT4(a0, a1, a2, a3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        group(i, SPT_F4(a0), SPT_F4(a1), SPT_F4(a2), SPT_F4(a3));
+                        SPT_LDS4(a0, a1, a2, a3, geom_base + j * 16u);
+                        SPT_WAIT4(c0, c1, c2, c3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        group(i + 4, SPT_F4(c0), SPT_F4(c1), SPT_F4(c2), SPT_F4(c3));
+                        SPT_LDS4(c0, c1, c2, c3, geom_base + j * 16u + 64u);
                     }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+#undef SPT_LDS4
+#undef SPT_WAIT4
+#undef SPT_F4
                 }
                 for (; i < P.n; ++i) {
                     const float4 g = s_geom[i];
@@ -548,8 +569,8 @@ static hipError_t launch_variant(const spt::KParams* P, uint32_t blocks, size_t 
 
 // Build variants: mat_lds (materials staged in LDS, n <= 256), guard (range-guarded sqrt in the hot loop, only
 // for degenerate scenes), diag (instrumented), bign (grouped wave-uniform det < 0 skip, large tables).
-// Large tables (materials in HBM) run 512-thread workgroups so that one LDS copy of the geometry serves 8 waves.
-static int g_big_block = 512;   // tuning knob (spt_set_tuning variant bit 9 selects 256)
+// Large tables (materials in HBM): 256- or 512-thread workgroups (one LDS copy of the geometry per 4 or 8 waves).
+static int g_big_block = 256;   // tuning knob (spt_set_tuning variant bit 9 selects 512)
 extern "C" void spt_k_set_big_block(int threads) { g_big_block = threads == 256 ? 256 : 512; }
 extern "C" int spt_k_block_threads_for(int mat_lds) { return mat_lds ? spt::kBlock : g_big_block; }
 
