@@ -278,9 +278,9 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
 
     // launch geometry: a persistent grid that fills the chip; the task queue makes any size correct
     const int mat_lds = (c->n <= 256) ? 1 : 0;
-    spt_k_set_big_block((c->variant & 0x200u) ? 512 : 256);   // A/B on the box: 256 is faster once the LDS reads are prefetched
-    const size_t lds = spt_k_lds_bytes(P.n_pad, mat_lds);
-    const int threads = spt_k_block_threads_for(mat_lds);
+    const int big_block = (c->variant & 0x200u) ? 512 : 256;   // A/B on the box: 256 is faster once the LDS reads are prefetched
+    const size_t lds = spt_k_lds_bytes(P.n_pad, mat_lds, big_block);
+    const int threads = spt_k_block_threads_for(mat_lds, big_block);
     uint32_t per_cu = c->blocks_per_cu;
     if (per_cu == 0) {
         const uint32_t by_lds = (uint32_t)((160u * 1024u) / lds);
@@ -296,7 +296,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
-    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, (c->needs_guard || !(cam_big <= 1e15f)) ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, (c->n > 24u) ? 1 : 0, st));
+    SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, (c->needs_guard || !(cam_big <= 1e15f)) ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, (c->n > 24u) ? 1 : 0, big_block, st));
     SPT_HIP(c, hipEventRecord(c->ev_mid, st));
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
     SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));

@@ -33,11 +33,10 @@ struct KParams {
 
 }  // namespace spt
 
-extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds);
-extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, hipStream_t stream);
+extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block);
+extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream);
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream);
 extern "C" int spt_k_block_threads(void);
-extern "C" int spt_k_block_threads_for(int mat_lds);
-extern "C" void spt_k_set_big_block(int threads);
+extern "C" int spt_k_block_threads_for(int mat_lds, int big_block);
 extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, uint32_t n, uint32_t w, hipStream_t stream);
 extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream);

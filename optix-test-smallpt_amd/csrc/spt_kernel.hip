@@ -569,28 +569,31 @@ static hipError_t launch_variant(const spt::KParams* P, uint32_t blocks, size_t 
 
 // Build variants: mat_lds (materials staged in LDS, n <= 256), guard (range-guarded sqrt in the hot loop, only
 // for degenerate scenes), diag (instrumented), bign (grouped wave-uniform det < 0 skip, large tables).
-// Large tables (materials in HBM): 256- or 512-thread workgroups (one LDS copy of the geometry per 4 or 8 waves).
-static int g_big_block = 256;   // tuning knob (spt_set_tuning variant bit 9 selects 512)
-extern "C" void spt_k_set_big_block(int threads) { g_big_block = threads == 256 ? 256 : 512; }
-extern "C" int spt_k_block_threads_for(int mat_lds) { return mat_lds ? spt::kBlock : g_big_block; }
+// Large tables (materials in HBM) run `big_block` = 256 or 512 threads per workgroup (one LDS copy of the
+// geometry per 4 or 8 waves); everything else runs 256.
+extern "C" int spt_k_block_threads_for(int mat_lds, int big_block) { return mat_lds ? spt::kBlock : (big_block == 512 ? 512 : 256); }
 
-extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds)
+extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block)
 {
-    const size_t block = (size_t)spt_k_block_threads_for(mat_lds);
+    const size_t block = (size_t)spt_k_block_threads_for(mat_lds, big_block);
     return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) + (size_t)spt::kStackEntries * spt::kStackFields * block * 4u;
 }
 
-extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, hipStream_t stream)
+extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream)
 {
-    const size_t lds = spt_k_lds_bytes(P->n_pad, mat_lds);
+    const size_t lds = spt_k_lds_bytes(P->n_pad, mat_lds, big_block);
+    const bool b512 = !mat_lds && big_block == 512;
     constexpr int B0 = spt::kBlock;
-    if (diag) return mat_lds ? launch_variant<true, false, true, false, B0>(P, blocks, lds, stream) : (g_big_block == 256 ? launch_variant<false, false, true, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, true, true, 512>(P, blocks, lds, stream));
+    if (diag) {
+        if (mat_lds) return launch_variant<true, false, true, false, B0>(P, blocks, lds, stream);
+        return b512 ? launch_variant<false, false, true, true, 512>(P, blocks, lds, stream) : launch_variant<false, false, true, true, 256>(P, blocks, lds, stream);
+    }
     if (mat_lds) {
         if (bign) return guard ? launch_variant<true, true, false, true, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, true, B0>(P, blocks, lds, stream);
         return guard ? launch_variant<true, true, false, false, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, false, B0>(P, blocks, lds, stream);
     }
-    if (g_big_block == 256) return guard ? launch_variant<false, true, false, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 256>(P, blocks, lds, stream);
-    return guard ? launch_variant<false, true, false, true, 512>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 512>(P, blocks, lds, stream);
+    if (b512) return guard ? launch_variant<false, true, false, true, 512>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 512>(P, blocks, lds, stream);
+    return guard ? launch_variant<false, true, false, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 256>(P, blocks, lds, stream);
 }
 
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream)
