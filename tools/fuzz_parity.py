@@ -1,0 +1,43 @@
+"""Randomised GPU-vs-oracle parity: random sphere tables (all materials, emitters, overlapping spheres, tiny and huge
+radii), random image sizes / spp / seeds / cameras.  Every case must be bit-identical, including bounce counts."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import optix_test_smallpt_amd as pkg
+import oracle_binding as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+r = pkg.Renderer(0)
+t0 = time.time(); cases = 0; bad = 0
+while time.time() - t0 < budget:
+    n = int(rs.choice([1, 2, 3, 5, 9, 17, 24, 25, 40, 100, 257, 600]))
+    rows = []
+    for i in range(n):
+        kind = rs.rand()
+        rad = float(10 ** rs.uniform(-1, 1.3)) if kind < 0.8 else float(10 ** rs.uniform(2, 5))
+        c = (rs.uniform(-20, 120), rs.uniform(-20, 100), rs.uniform(-50, 250))
+        if kind >= 0.8:   # huge "wall" sphere placed so that the camera is inside or just outside
+            c = tuple(float(v) for v in (np.array([50, 40, 80]) + (rs.randn(3) / np.linalg.norm(rs.randn(3)+1e-9)) * rad * rs.uniform(0.9, 1.1)))
+        e = (0, 0, 0) if rs.rand() < 0.8 else tuple(rs.uniform(0, 5, 3))
+        col = tuple(rs.uniform(0, 1, 3)) if rs.rand() < 0.9 else (0, 0, 0)
+        if rs.rand() < 0.05: col = (1.0, 1.0, 1.0)
+        rows.append((rad, c, e, col, int(rs.choice([0, 0, 0, 1, 2]))))
+    sc = pkg.make_spheres(rows)
+    w, h = int(rs.randint(1, 70)), int(rs.randint(1, 50))
+    samps = int(rs.choice([1, 1, 2, 3, 7]))
+    seed = int(rs.randint(0, 2**31)) * int(rs.choice([1, 2**20]))
+    cam = None if rs.rand() < 0.6 else pkg.pinhole_camera(org=(50, 45, 250), vz=(0, 0, -1))
+    norm = bool(rs.rand() < 0.5)
+    r.set_scene(sc)
+    img, st = r.render(w, h, samps, seed=seed, normalise=norm, camera=cam)
+    ref, rst = orc.render(sc, w, h, samps, seed=seed, normalise=norm, camera=cam)
+    ok = np.array_equal(img, ref, equal_nan=True) and st["bounces"] == rst["bounces"] and st["max_depth_kills"] == rst["max_depth_kills"]
+    cases += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH case", cases, dict(n=n, w=w, h=h, samps=samps, seed=seed, pinhole=cam is not None, norm=norm),
+              "pixels differ", int((img != ref).any(axis=-1).sum()), "bounces", st["bounces"], rst["bounces"], flush=True)
+print(f"fuzz: {cases} cases, {bad} mismatches, {time.time()-t0:.0f} s")
+sys.exit(1 if bad else 0)
