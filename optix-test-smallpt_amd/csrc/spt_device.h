@@ -70,6 +70,7 @@ __device__ __forceinline__ float sqrt_exact(float x)
 // v_rcp_f32 (1 ulp) + two FMA Newton steps give RN(1/y) for every binary32 y whose mantissa is not all
 // ones (Markstein; enumerated for all 2^23 mantissas in tools/verify_exact_math.c).  The all-ones mantissa
 // and exponents where the residual could under/overflow take the compiler's IEEE division (rare branch).
+template <bool RANGE_CHECK = true>
 __device__ __forceinline__ float rcp_exact(float y)
 {
     float r = __builtin_amdgcn_rcpf(y);
@@ -78,8 +79,10 @@ __device__ __forceinline__ float rcp_exact(float y)
     e = __builtin_fmaf(-y, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
     const uint32_t u = __float_as_uint(y);
-    // safe range: 2^-100 <= y < 2^100 (positive, normal) and mantissa != 0x7FFFFF
-    const bool slow = ((u - 0x0D800000u) >= (0x71800000u - 0x0D800000u)) || ((u & 0x7FFFFFu) == 0x7FFFFFu);
+    // safe range: 2^-100 <= y < 2^100 (positive, normal) and mantissa != 0x7FFFFF.  RANGE_CHECK = false is used
+    // where the caller guarantees the range (lengths of unit-scale vectors / sphere radii validated by the host).
+    bool slow = (u & 0x7FFFFFu) == 0x7FFFFFu;
+    if (RANGE_CHECK) slow = slow || ((u - 0x0D800000u) >= (0x71800000u - 0x0D800000u));
     if (__builtin_expect(slow, 0)) r = 1.0f / y;
     return r;
 }
@@ -89,7 +92,7 @@ template <bool GUARD = true>
 __device__ __forceinline__ f3 normalize(f3 v)
 {
     const float q = dot(v, v);
-    const float inv = rcp_exact(GUARD ? sqrt_exact(q) : sqrt_fix(q));
+    const float inv = GUARD ? rcp_exact<true>(sqrt_exact(q)) : rcp_exact<false>(sqrt_fix_int(q));
     return v * inv;
 }
 
