@@ -143,7 +143,8 @@ int  spt_diag(spt_ctx* ctx, unsigned long long* out15);
 
 /* Numerics self-test of the kernel's exact-math helpers (host arrays in/out, n elements):
  * op 0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact, 4 (float)((double)x / w) by the FMA sequence,
- * 5/6 sin/cos(2*pi*x) (D17), 7 rng_draw keyed by bits(x).  Used by tests/test_gpu_math.py. */
+ * 5/6 sin/cos(2*pi*x) (D17), 7 rng_draw keyed by bits(x), 8/9 sin/cos from the raw draw bits carried in x.
+ * Used by tests/test_gpu_math.py. */
 int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32_t n, uint32_t w);
 
 /* Image output helpers kept from the reference: toInt (smallpt.cpp:52), flipY (:125-134) and the

@@ -112,6 +112,15 @@ __device__ __forceinline__ uint32_t rng_base(uint32_t k0, uint32_t branch, uint3
 {
     return k0 + ((branch << 29) | (depth << 2)) * kGolden;
 }
+// raw 32 random bits of a draw; the uniform is (bits >> 8) * 2^-24
+__device__ __forceinline__ uint32_t rng_draw_bits(uint32_t x, uint32_t k1)
+{
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x += k1;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
 __device__ __forceinline__ float rng_draw(uint32_t x, uint32_t k1)
 {
     x ^= x >> 16; x *= 0x21f0aaadu;
@@ -142,6 +151,21 @@ __device__ __forceinline__ float sin_quarter(float z)
     p = p * z2 + c3;
     p = p * z2 + c1;
     return p * z;
+}
+// Same function evaluated from the draw's raw bits: u = k * 2^-24 with k = bits >> 8, so 4u = k * 2^-22,
+// q = floor(4u) = bits >> 30 and f = 4u - q = (k mod 2^22) * 2^-22 -- bit-identical to the float route below
+// (every step there is exact), with two conversions fewer; signs are applied by XOR-ing the sign bit.
+__device__ __forceinline__ void sincos2pi_bits(uint32_t bits, float& s, float& c)
+{
+    const uint32_t q = bits >> 30;
+    const float f = (float)((bits << 2) >> 10) * 0x1p-22f;
+    const float S = sin_quarter(f);
+    const float C = sin_quarter(1.0f - f);
+    const bool odd = (q & 1u) != 0u;
+    const float s0 = odd ? C : S;
+    const float c0 = odd ? S : C;
+    s = __uint_as_float(__float_as_uint(s0) ^ ((q & 2u) << 30));            // q: 0 S, 1 C, 2 -S, 3 -C
+    c = __uint_as_float(__float_as_uint(c0) ^ (((q + 1u) & 2u) << 30));      // q: 0 C, 1 -S, 2 -C, 3 S
 }
 __device__ __forceinline__ void sincos2pi(float u, float& s, float& c)
 {

@@ -371,11 +371,11 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                     const f3 no = hx + nl * 0.02f;                                     // :172 (D3)
                     f3 nd;
                     if (refl == 0) {                                                   // DIFF :208-215
-                        const float u1 = rng_draw(p.rbase + kGolden, k1);
+                        const uint32_t u1bits = rng_draw_bits(p.rbase + kGolden, k1);
                         const float r2 = rng_draw(p.rbase + 2u * kGolden, k1);
                         const float r2s = sqrt_fix_int(r2);                               // r2 in {0} U [2^-24, 1)
                         float sn, cs;
-                        sincos2pi(u1, sn, cs);                                          // D17
+                        sincos2pi_bits(u1bits, sn, cs);                                 // D17, from the raw bits of u1
                         const f3 ww = nl;
                         // u = normalize(cross(|w.x| > .1 ? (0,1,0) : (1,0,0), w)), :211.  (double)fabs(w.x) > .1 <=>
                         // fabsf(w.x) >= 0.1f.  cross((0,1,0),w) = (w.z, 0, -w.x); cross((1,0,0),w) = (0, -w.z, w.y):
@@ -534,6 +534,8 @@ __global__ void selftest_math(int op, const float* __restrict__ in, float* __res
     }
     case 5: { float sn, cs; sincos2pi(x, sn, cs); y = sn; break; }
     case 6: { float sn, cs; sincos2pi(x, sn, cs); y = cs; break; }
+    case 8: { float sn, cs; sincos2pi_bits(__float_as_uint(x), sn, cs); y = sn; break; }   // x carries the raw bits
+    case 9: { float sn, cs; sincos2pi_bits(__float_as_uint(x), sn, cs); y = cs; break; }
     default: y = rng_draw(__float_as_uint(x), 0x9ABCDEF0u); break;
     }
     out[i] = y;

@@ -69,6 +69,13 @@ def test_sincos_and_rng_match_oracle(renderer, oracle):
     for i, v in enumerate(u):
         L.orc_sincos2pi(float(v), C.byref(s), C.byref(c))
         assert (f32(s.value), f32(c.value)) == (sn[i], cs[i])
+    # the kernel's bit-level variant (q, f taken from the raw draw) must equal the float route for every draw value
+    bits = np.concatenate([np.random.RandomState(9).randint(0, 1 << 32, size=1 << 20, dtype=np.uint64).astype(np.uint32),
+                           np.array([0, 0xFF, 0x100, 0x3FFFFFFF, 0x40000000, 0x7FFFFFFF, 0x80000000, 0xBFFFFFFF, 0xC0000000,
+                                     0xFFFFFFFF, 0xFFFFFF00], dtype=np.uint32)])
+    uu = ((bits >> np.uint32(8)).astype(np.float32) * f32(2.0**-24))
+    assert np.array_equal(renderer.selftest_math(8, bits.view(np.float32)).view(np.uint32), renderer.selftest_math(5, uu).view(np.uint32))
+    assert np.array_equal(renderer.selftest_math(9, bits.view(np.float32)).view(np.uint32), renderer.selftest_math(6, uu).view(np.uint32))
     keys = np.random.RandomState(3).randint(0, 1 << 31, size=5000, dtype=np.uint32)
     y = renderer.selftest_math(7, keys.view(np.float32))
     for i, k in enumerate(keys[:2000]):
