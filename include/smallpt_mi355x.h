@@ -116,7 +116,8 @@ int  spt_render(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
 
 /* Renders rows [row_begin, row_begin+row_count) of the w x h image into d_out_rgb, a DEVICE pointer
  * to row_count*w*3 floats on this context's device.  The launch is enqueued on `hip_stream`
- * (a hipStream_t cast to void*; NULL = the context's own stream) and returns without waiting.
+ * (a hipStream_t cast to void*; NULL = the context's own stream) and returns without waiting for it
+ * (a context keeps one launch in flight: a call made while the previous launch is still running first waits for it).
  * Pixel/sample RNG keys use the GLOBAL pixel index, so any row partition over any number of GPUs
  * yields the same image.  Call spt_sync() before reading stats. */
 int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,

@@ -386,9 +386,9 @@ int spt_selftest_math(spt_ctx* c, int op, const float* in, float* out, uint32_t 
     if (!in || !out || !n || !w) return c->fail("spt_selftest_math: bad argument");
     SPT_HIP(c, hipSetDevice(c->device));
     float *d_in = nullptr, *d_out = nullptr;
-    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * 4));
-    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 4));
-    hipError_t e = hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = spt_k_selftest(op, d_in, d_out, n, w, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost);
