@@ -28,3 +28,18 @@ def test_bench_json_line_contract():
         assert k in r, k
     assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert j["value"] > 100 and j["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_throughput_floor():
+    """Regression guard: the headline workload at reduced spp must stay well above the first correct kernel
+    (4.7 Gsamples/s at 1024 spp; 256 spp adds task-fetch overhead, so the floor is conservative)."""
+    sys.path.insert(0, ROOT)
+    import optix_test_smallpt_amd as pkg
+    r = pkg.Renderer(0)
+    r.set_scene(pkg.cornell9())
+    r.render(1024, 768, 64)
+    best = min(r.render(1024, 768, 64)[1]["kernel_ms"] for _ in range(3))
+    rate = 1024 * 768 * 256 / best / 1e3
+    r.close()
+    assert rate > 4500, f"{rate:.0f} Msamples/s"

@@ -137,6 +137,19 @@ def test_progressive_accumulation_matches_frame_sum(pkg, renderer, oracle):
     assert prog.frames == 1 and np.array_equal(prog.accum.cpu().numpy(), ref)
 
 
+def test_monte_carlo_convergence(pkg, renderer):
+    """Estimator sanity on the GPU path: images from independent seeds agree within Monte-Carlo noise, and the
+    noise falls like 1/sqrt(spp) (a biased RNG stream or a broken roulette compensation would not)."""
+    renderer.set_scene(pkg.cornell9(12.0))
+    def img(samps, seed):
+        return renderer.render(96, 72, samps, seed=seed, normalise=True)[0].astype(np.float64)
+    lo = np.sqrt(((img(4, 1) - img(4, 2)) ** 2).mean())        # 16 spp
+    hi = np.sqrt(((img(64, 3) - img(64, 4)) ** 2).mean())      # 256 spp
+    assert 2.5 < lo / hi < 6.0, (lo, hi)                       # expected ratio sqrt(16) = 4
+    ref = img(256, 9)
+    assert abs(img(64, 5).mean() / ref.mean() - 1) < 0.02      # no brightness drift between seeds / spp
+
+
 def test_empty_scene_is_black(pkg, renderer):
     renderer.set_scene(pkg.make_spheres([]))
     img, st = renderer.render(16, 8, 2)
