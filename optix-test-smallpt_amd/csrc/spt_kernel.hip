@@ -4,14 +4,19 @@
 // (smallpt.cpp:349-356 / :779-807) by one launch in which every lane owns a path from camera ray to
 // termination:
 //   * work unit ("task") = one jitter cell of one pixel (pixel*4 + sy*2+sx, smallpt.cpp:299-309);
-//     a lane runs the task's `samps` samples in order and writes ONE 16-byte cell sum.  Lanes pull
-//     tasks from a global atomic queue (wave-aggregated fetch), so there is no per-tile tail.
+//     a lane runs the task's `samps` samples in order and writes ONE 16-byte cell sum.  Lanes take
+//     tasks from their wave's private chunk of 64 task ids; a wave touches the global queue word once
+//     per chunk, so there is neither a per-tile tail nor contention on the queue.
 //   * the recursive radiance() / the wavefront path buffers become an iterative loop with path
-//     regeneration; the glass split (smallpt.cpp:248-254) uses a <=3-entry per-lane stack in LDS.
+//     regeneration (camera rays are generated in batches into a 2-entry register queue); the glass
+//     split (smallpt.cpp:248-254) uses a <=3-entry per-lane stack in LDS.
 //   * the sphere table is staged in LDS once per workgroup ({center, r*r} 16 B per sphere) and read
 //     with wave-uniform (broadcast) ds_read_b128 in the closest-hit loop (smallpt.cpp:54-70).
 //   * RNG is counter-based (D7), so the image does not depend on grid size, scheduling or GPU count.
-// A second tiny kernel folds the four cell sums of a pixel in fixed order and normalises (D9).
+//   * every float operation is one IEEE binary32 operation (-ffp-contract=off); the short sqrt /
+//     reciprocal sequences of spt_device.h are proven correctly rounded (tools/verify_exact_math.c).
+// A second small kernel folds the four cell sums of a pixel in fixed order, normalises and writes the
+// packed float3 rows with coalesced 16-byte stores (D9).
 #include "spt_device.h"
 #include "spt_kernel.h"
 
