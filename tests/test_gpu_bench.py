@@ -43,3 +43,22 @@ def test_throughput_floor():
     rate = 1024 * 768 * 256 / best / 1e3
     r.close()
     assert rate > 4500, f"{rate:.0f} Msamples/s"
+
+
+@pytest.mark.gpu
+def test_two_rank_weak_scaling_rehearsal():
+    """The N > 1 code path of bench.py (row bands with global pixel indices, gather to rank 0, max-over-ranks timing)
+    with two ranks sharing the box's GPU and gloo as transport (SPT_BENCH_BACKEND=gloo); the driver's runs use RCCL."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SPT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--samps", "4"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # only rank 0 prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["height"] == 2 * 768 and j["config"]["rows_per_gpu"] == 768
+    assert "cpu_baseline" not in j              # rank 0 at N = 1 only
