@@ -198,6 +198,10 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
         if (__ballot(starved) != 0ull) {
             if (DIAG) { ++runs_c1; lanes_c1 += __popcll(__ballot(task_valid && s_gen < P.samps && rcount < 2u)); }
             if (task_valid && s_gen < P.samps && rcount < 2u) {
+                if (nbounce > 0x40000000u) {           // keep the 32-bit per-lane counter from wrapping at extreme spp
+                    atomicAdd(&P.counters[0], (unsigned long long)nbounce);
+                    nbounce = 0;
+                }
                 const uint32_t index_in_pixel = cell * P.samps + s_gen;      // smallpt.cpp:306
                 CamRay e;
                 e.k0 = mix32(p0 ^ (index_in_pixel * kGolden));
