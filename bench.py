@@ -54,13 +54,46 @@ def cpu_baseline(pkg, budget_s=15.0):
             "bounces_per_sample": round(st["bounces"] / st["samples"], 4)}
 
 
+def d2h_inclusive(r, samps, steps):
+    """spt_render: kernel + finalize + copy of the 9.4 MB float3 image to (pageable) host memory, host wall clock."""
+    r.render(W, H_PER_GPU, samps, seed=0, normalise=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, st = r.render(W, H_PER_GPU, samps, seed=0, normalise=True)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(st["samples"] / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+            "note": "same step via spt_render: includes the D2H copy of the w*h*3 float image to pageable host memory"}
+
+
+def interactive(pkg, r, dev, frames=200):
+    """Render-thread loop of the viewer (smallpt.cpp:895-942) at the reference's window size: Cornell-9 seen by the
+    pinhole Camera{vx,vy,vz,org,near=1} placed at the smallpt eye point, 1 sample per jitter cell per frame."""
+    w, h, samps = 1280, 720, 1
+    cam = pkg.pinhole_camera(vx=(1, 0, 0), vz=(0, 0, -1), org=(50, 52, 295.6), near=1.0)
+    prog = pkg.ProgressiveRenderer(r, w, h, samps, camera=cam)
+    import torch
+    for _ in range(10):
+        prog.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        prog.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    return {"workload": f"Cornell-9, {w}x{h}, 4 spp per frame (1 per jitter cell), pinhole camera + box-in-cell sampling, "
+                        f"frame accumulated in HBM, {frames} frames", "frames_per_s": round(1.0 / dt, 1),
+            "ms_per_frame": round(dt * 1e3, 4), "value": round(w * h * 4 * samps / dt / 1e6, 1), "unit": "Msamples/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the d2h_inclusive and interactive measurements (profiling runs)")
     ap.add_argument("--samps", type=int, default=SAMPS, help=argparse.SUPPRESS)   # dev only; default = config
+    ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help=argparse.SUPPRESS)   # dev only: kernel A/B (csrc/spt_internal.h)
     args = ap.parse_args()
 
     import torch
@@ -93,6 +126,8 @@ def main():
     samps = args.samps
     r = pkg.Renderer(dev_index)
     r.set_scene(pkg.cornell9())
+    if args.variant:
+        r.set_tuning(0, args.variant)
     band = torch.empty((count, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -169,6 +204,13 @@ def main():
                                               "achieved_GBps": round(count * W * (64 + 12) / f_s / 1e9, 1),
                                               "peak_GBps": HBM_PEAK_GBPS}},
         }
+        if world == 1 and not args.no_extras:
+            # Outside the timed region: (1) the same step through spt_render, i.e. INCLUDING the framebuffer D2H copy into
+            # host memory ("kernel + framebuffer D2H/gather"); never `value`, reported beside it.
+            # (2) the reference's live use (smallpt.cpp:844-846,922): 1280x720, 1 sample per jitter cell per frame,
+            # pinhole Camera + box-in-cell sampling, device-resident accumulation -- frames/s of the render-thread loop.
+            out["d2h_inclusive"] = d2h_inclusive(r, samps, max(1, min(3, args.steps)))
+            out["interactive"] = interactive(pkg, r, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
         print(json.dumps(out), flush=True)

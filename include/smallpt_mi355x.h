@@ -133,21 +133,6 @@ int  spt_accumulate_device(spt_ctx* ctx, void* d_accum, const void* d_frame, uin
 /* Waits for the last launch of this context and fills stats (may be NULL). */
 int  spt_sync(spt_ctx* ctx, spt_stats* stats);
 
-/* Tuning knobs (0 = default).  blocks_per_cu caps the persistent grid; variant bits 0..7 = number of
- * waiting lanes that triggers a wave's glass-shading pass (0 = default 8), bit 8 = instrumented kernel
- * build (see spt_diag), bit 9 = 512-thread workgroups for tables above 256 spheres.  Results never depend
- * on these. */
-int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
-/* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
- * out15[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters. */
-int  spt_diag(spt_ctx* ctx, unsigned long long* out15);
-
-/* Numerics self-test of the kernel's exact-math helpers (host arrays in/out, n elements):
- * op 0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact, 4 (float)((double)x / w) by the FMA sequence,
- * 5/6 sin/cos(2*pi*x) (D17), 7 rng_draw keyed by bits(x), 8/9 sin/cos from the raw draw bits carried in x.
- * Used by tests/test_gpu_math.py. */
-int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32_t n, uint32_t w);
-
 /* Image output helpers kept from the reference: toInt (smallpt.cpp:52), flipY (:125-134) and the
  * ASCII P3 writer (:136-142).  rgb is w*h*3 floats, row 0 = bottom; the file gets the flipped image. */
 int  spt_to_int(float x);

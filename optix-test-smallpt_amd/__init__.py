@@ -3,7 +3,7 @@ Celeborn2BeAlive/optix-test-smallpt.  The compute path is the gfx950 megakernel 
 include/smallpt_mi355x.h (csrc/); this package is the thin host-side mirror of the reference's
 scene structs and render entry points.  Import name: ``optix_test_smallpt_amd`` (see the shim at
 the repository root)."""
-from ._lib import LIB_PATH, SYMBOLS, SptCamera, SptSphere, SptStats, load_library  # noqa: F401
+from ._lib import INTERNAL_SYMBOLS, LIB_PATH, SYMBOLS, SptCamera, SptSphere, SptStats, load_library  # noqa: F401
 from .renderer import (FLAG_NORMALISE, ProgressiveRenderer, Renderer, SptError, pinhole_camera,  # noqa: F401
                        smallpt_camera, to_int, write_ppm)
 from .scene import (DIFF, REFR, SPEC, SPHERE_DTYPE, cornell9, make_spheres, random_spheres,  # noqa: F401

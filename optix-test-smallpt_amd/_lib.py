@@ -44,11 +44,17 @@ SYMBOLS = {
                                          C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
     "spt_accumulate_device": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _P]),
     "spt_sync": (C.c_int, [_P, C.POINTER(SptStats)]),
+    "spt_to_int": (C.c_int, [C.c_float]),
+    "spt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+}
+
+# test / tuning hooks declared in csrc/spt_internal.h (not part of the drop-in boundary)
+INTERNAL_SYMBOLS = {
     "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_diag": (C.c_int, [_P, C.POINTER(C.c_uint64 * 15)]),
     "spt_selftest_math": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint32, C.c_uint32]),
-    "spt_to_int": (C.c_int, [C.c_float]),
-    "spt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+    "spt_set_watchdog": (C.c_int, [_P, C.c_double]),
+    "spt_last_kernel": (C.c_int, [_P]),
 }
 
 _lib = None
@@ -64,7 +70,7 @@ def load_library():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in {**SYMBOLS, **INTERNAL_SYMBOLS}.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

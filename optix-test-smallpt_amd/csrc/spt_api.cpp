@@ -1,6 +1,7 @@
 // spt_api.cpp -- the C-ABI of include/smallpt_mi355x.h on top of the gfx950 megakernel.
 // Host-side only: scene upload, launch geometry, HIP-event timing, statistics, image output.
 #include "../../include/smallpt_mi355x.h"
+#include "spt_internal.h"
 #include "spt_kernel.h"
 
 #include <chrono>
@@ -43,6 +44,11 @@ struct spt_ctx {
     float4* d_mat = nullptr;
     uint32_t scene_cap = 0;
     bool needs_guard = false;      // r*r < 2^-60 or coordinates above 1e15: the hot-loop sqrt keeps its range guard
+    bool pool_ok = false;          // scene qualifies for the material-sorted pool kernel (spt_pool.hip)
+    float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
+    size_t stack_cap = 0;          // in floats
+    bool last_was_pool = false;
+    unsigned long long pool_stats[10] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
     size_t cells_cap = 0;          // in float4
@@ -53,6 +59,7 @@ struct spt_ctx {
     // tuning
     uint32_t blocks_per_cu = 0;
     uint32_t variant = 0;
+    unsigned long long watchdog_ticks = 0;   // pool kernel: s_memtime ticks (shader cycles) per launch; 0 = no watchdog
     // last launch
     bool pending = false;
     spt_stats last{};
@@ -139,6 +146,7 @@ void spt_destroy(spt_ctx* c)
     if (c->d_mat) (void)hipFree(c->d_mat);
     if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_stack) (void)hipFree(c->d_stack);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -183,8 +191,12 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
         geom[i] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius * sp.radius);
         const float pmax = std::fmax(std::fmax(sp.color[0], sp.color[1]), sp.color[2]);
         const float inv = 1.0f / pmax;
+        // refl in bits 1:0; bit 2 = "emission is not exactly zero" (the pool kernel skips the + weight*0 of smallpt.cpp:179
+        // for non-emissive hits, which is exact for finite weights)
+        const bool emissive = !(sp.emission[0] == 0.f && sp.emission[1] == 0.f && sp.emission[2] == 0.f);
+        const int32_t rb = sp.refl | (emissive ? 4 : 0);
         float reflbits;
-        std::memcpy(&reflbits, &sp.refl, 4);
+        std::memcpy(&reflbits, &rb, 4);
         mat[3 * i + 0] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], reflbits);
         mat[3 * i + 1] = make_float4(sp.color[0], sp.color[1], sp.color[2], pmax);
         mat[3 * i + 2] = make_float4(sp.color[0] * inv, sp.color[1] * inv, sp.color[2] * inv, 0.0f);
@@ -200,6 +212,12 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
                                     std::fmax(std::fabs(s[i].center[2]), std::fabs(s[i].radius)));
         if (!(s[i].radius * s[i].radius >= 0x1p-60f) || !(big <= 1e15f)) c->needs_guard = true;
     }
+    // Pool kernel: unrolled closest hit (<= 24 spheres), un-guarded sqrt, and path weights that only the glass factors
+    // can push out of the finite range (colours in [0,1], finite emission) -- it tracks that case with a flag.
+    c->pool_ok = n <= (uint32_t)spt_pool_max_spheres() && !c->needs_guard;
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!(s[i].color[k] >= 0.f && s[i].color[k] <= 1.f) || !(std::fabs(s[i].emission[k]) <= 3e38f)) c->pool_ok = false;
     return 0;
 }
 
@@ -276,6 +294,50 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     P.geom = c->d_geom; P.mat = c->d_mat;
     P.cells = c->d_cells; P.queue = c->d_queue; P.counters = c->d_counters;
 
+    const float cam_big = std::fmax(std::fmax(std::fabs(cam->origin[0]), std::fabs(cam->origin[1])),
+                                    std::fmax(std::fabs(cam->origin[2]), std::fabs(cam->push)));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
+
+    // ---- material-sorted pool kernel (spt_pool.hip): small tables, regular scenes; variant bit 10 forces the megakernel ----
+    if (c->pool_ok && cam_big <= 1e15f && !(c->variant & 0x500u)) {
+        const uint32_t psel = (c->variant >> 11) & 3u;
+        const int pool = psel == 1 ? 96 : (psel == 2 ? 192 : 128);
+        const size_t lds = spt_pool_lds_bytes(P.n, pool);
+        uint32_t per_cu = c->blocks_per_cu;
+        if (per_cu == 0) {
+            const uint32_t by_lds = (uint32_t)((160u * 1024u) / lds);
+            per_cu = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
+        }
+        uint64_t blocks = (uint64_t)c->cu_count * per_cu;
+        const uint64_t needed = (ntasks + 255) / 256;
+        if (blocks > needed) blocks = needed;
+        if (blocks < 1) blocks = 1;
+        const size_t need_stack = spt_pool_stack_floats((uint32_t)blocks, pool);
+        if (need_stack > c->stack_cap) {
+            if (c->d_stack) (void)hipFree(c->d_stack);
+            c->d_stack = nullptr; c->stack_cap = 0;
+            SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_stack), need_stack * sizeof(float)));
+            c->stack_cap = need_stack;
+        }
+        P.stack = c->d_stack;
+        P.watchdog_ticks = c->watchdog_ticks;
+        SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
+        SPT_HIP(c, hipEventRecord(c->ev_start, st));
+        SPT_HIP(c, spt_pool_launch(&P, (uint32_t)blocks, pool, st));
+        SPT_HIP(c, hipEventRecord(c->ev_mid, st));
+        SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
+        SPT_HIP(c, hipEventRecord(c->ev_stop, st));
+        c->pending = true;
+        c->last_was_pool = true;
+        c->last = spt_stats{};
+        c->last.samples = npix * 4ull * samps;
+        c->last.grid_blocks = (uint32_t)blocks;
+        c->last.block_threads = 256;
+        return 0;
+    }
+    c->last_was_pool = false;
+
     // launch geometry: a persistent grid that fills the chip; the task queue makes any size correct
     const int mat_lds = (c->n <= 256) ? 1 : 0;
     const int big_block = (c->variant & 0x200u) ? 512 : 256;   // A/B on the box: 256 is faster once the LDS reads are prefetched
@@ -291,14 +353,10 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
 
-    const float cam_big = std::fmax(std::fmax(std::fabs(cam->origin[0]), std::fabs(cam->origin[1])),
-                                    std::fmax(std::fabs(cam->origin[2]), std::fabs(cam->push)));
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
     SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, (c->needs_guard || !(cam_big <= 1e15f)) ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, (c->n > 24u) ? 1 : 0, big_block, st));
     SPT_HIP(c, hipEventRecord(c->ev_mid, st));
-    const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
     SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
     SPT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->pending = true;
@@ -326,6 +384,11 @@ int spt_sync(spt_ctx* c, spt_stats* stats)
         c->last.max_depth_kills = ctr[1];
         if (c->variant & 0x100u) SPT_HIP(c, hipMemcpy(c->diag, c->d_counters + 2, sizeof c->diag, hipMemcpyDeviceToHost));
         c->pending = false;
+        if (c->last_was_pool) {
+            SPT_HIP(c, hipMemcpy(c->pool_stats, c->d_counters + 2, sizeof c->pool_stats, hipMemcpyDeviceToHost));
+            if (c->pool_stats[6] != 0)
+                return c->fail("spt_sync: %llu waves hit the kernel watchdog; the image is incomplete", c->pool_stats[6]);
+        }
     }
     if (stats) *stats = c->last;
     return 0;
@@ -374,9 +437,23 @@ int spt_accumulate_device(spt_ctx* c, void* d_accum, const void* d_frame, uint64
 int spt_diag(spt_ctx* c, unsigned long long* out15)
 {
     if (!c || !out15) return 1;
+    if (c->last_was_pool) {
+        std::memset(out15, 0, sizeof c->diag);
+        std::memcpy(out15, c->pool_stats, sizeof c->pool_stats);
+        return 0;
+    }
     std::memcpy(out15, c->diag, sizeof c->diag);
     return 0;
 }
+
+int spt_set_watchdog(spt_ctx* c, double seconds)
+{
+    if (!c) return 1;
+    c->watchdog_ticks = seconds > 0 ? (unsigned long long)(seconds * 2.4e9) : 0ull;   // s_memtime ticks are shader cycles (<= 2.4 GHz)
+    return 0;
+}
+
+int spt_last_kernel(spt_ctx* c) { return c ? (c->last_was_pool ? 1 : 0) : -1; }
 
 // Numerics self-test: runs device helper `op` (0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact,
 // 4 double division by w, 5/6 sin/cos(2*pi*x), 7 rng_draw(bits(x))) over n host floats.

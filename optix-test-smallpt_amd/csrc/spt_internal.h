@@ -1,0 +1,41 @@
+/*
+ * spt_internal.h -- test / tuning hooks of libsmallpt_mi355x.so.  NOT part of the drop-in boundary
+ * (include/smallpt_mi355x.h): nothing here replaces a reference interface.  Used by tests/, tools/ and
+ * bench.py's A/B switches only; results never depend on any of these knobs.
+ */
+#ifndef SPT_INTERNAL_H
+#define SPT_INTERNAL_H
+
+#include "../../include/smallpt_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning knobs (0 = default).  blocks_per_cu caps the persistent grid; variant bits 0..7 = number of
+ * waiting lanes that triggers a wave's glass-shading pass (0 = default 8), bit 8 = instrumented kernel
+ * build (see spt_diag), bit 9 = 512-thread workgroups for tables above 256 spheres, bit 10 = force the megakernel where the pool kernel
+ * would run, bits 12:11 = pool slots per wave (0: 128, 1: 96, 2: 192).  Results never depend on these. */
+int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
+/* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
+ * out15[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters. */
+int  spt_diag(spt_ctx* ctx, unsigned long long* out15);
+
+/* Pool kernel only: a wave gives up `seconds` after its start (0 = never; default).  A launch in which that happened
+ * makes spt_sync fail instead of returning an incomplete image.  Tests set a few seconds so that a scheduling bug
+ * cannot hang the GPU box. */
+int  spt_set_watchdog(spt_ctx* ctx, double seconds);
+/* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip).
+ * After a pool launch spt_diag returns out15[0..2] = batches per class (GEN, DIFF, REFR), [3..5] = lanes per class. */
+int  spt_last_kernel(spt_ctx* ctx);
+
+/* Numerics self-test of the kernel's exact-math helpers (host arrays in/out, n elements):
+ * op 0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact, 4 (float)((double)x / w) by the FMA sequence,
+ * 5/6 sin/cos(2*pi*x) (D17), 7 rng_draw keyed by bits(x), 8/9 sin/cos from the raw draw bits carried in x.
+ * Used by tests/test_gpu_math.py. */
+int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32_t n, uint32_t w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPT_INTERNAL_H */

@@ -29,6 +29,10 @@ struct KParams {
     float4* cells;           // ntasks cell sums
     uint32_t* queue;         // task queue head (zeroed before launch)
     unsigned long long* counters;  // [0] bounces, [1] depth-cap kills, [2..16] DIAG phase times / lane counts
+                                   // pool kernel: [2..4] batches per class (GEN, DIFF, REFR), [5..7] lanes per class, [8] watchdog hits
+    // pool kernel (spt_pool.hip) only
+    float* stack;                  // pending transmitted children: waves x 3 entries x 12 words x pool slots
+    unsigned long long watchdog_ticks;  // s_memtime ticks after which a wave gives up (0 = never)
 };
 
 }  // namespace spt
@@ -39,4 +43,8 @@ extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t n
 extern "C" int spt_k_block_threads(void);
 extern "C" int spt_k_block_threads_for(int mat_lds, int big_block);
 extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, uint32_t n, uint32_t w, hipStream_t stream);
+extern "C" size_t spt_pool_lds_bytes(uint32_t n, int pool);
+extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool);
+extern "C" int spt_pool_max_spheres(void);
+extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, int pool, hipStream_t stream);
 extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream);

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
             const float4 me = mats[3 * hit_inst + 0];         // emission.xyz, refl
             const float4 gh = s_geom[hit_inst];
             const float4 mc = mats[3 * hit_inst + 1];         // color.xyz, pmax
-            const int refl = __float_as_int(me.w);
+            const int refl = __float_as_int(me.w) & 3;          // bit 2 = "emissive" flag for the pool kernel
             f3 hx, n, nl, f;
             bool cont = shade_common<GUARD>(p, hit_t, gh, me, mc, mats, hit_inst, k1, acc, hx, n, nl, f);
             if (cont) {

@@ -1,0 +1,488 @@
+// spt_pool.hip -- material-sorted persistent path-tracing kernel for gfx950 (MI355X), small sphere tables.
+//
+// Same algorithm and arithmetic as spt_kernel.hip (the per-bounce host loop { Intersector::traceRays ->
+// shadePaths -> compact } of smallpt.cpp:349-356 / :779-807 collapsed into one launch), different scheduling:
+//
+//   * every WAVE owns a private pool of P path slots in LDS (P = 2 x 64 by default).  A slot is one task
+//     (= one jitter cell of one pixel, smallpt.cpp:299-309) with at most one path in flight, so emission
+//     events of a cell are accumulated in exactly the order of D9 (sample-ascending, DFS pre-order).
+//   * slots wait in one of three wave-private LIFO lists by the NEXT thing their path needs:
+//       GEN   start the next camera sample / pop a pending transmitted child / fetch a new task
+//       DIFF  shade a DIFF or SPEC hit   (smallpt.cpp:208-223)
+//       REFR  shade a glass hit          (smallpt.cpp:225-263)
+//     Each iteration the wave pulls up to 64 slots of ONE class, runs that class's code with every lane
+//     active, then -- in the same lanes -- the closest-hit query (smallpt.cpp:54-70) and the class-independent
+//     part of shadePaths (emission, Russian roulette, weight update, :170-198), and pushes each slot onto
+//     the list of its next class.  The megakernel of spt_kernel.hip runs DIFF shading at ~69 % and glass
+//     shading at ~18 % lane utilisation because a lane owns its path; here a batch is >= 93 % full
+//     (P = 128: three lists hold 128 entries, see tools/pool_sim.py) at the price of one LDS round trip of
+//     the 48-byte path state per bounce.  No cross-wave communication, no barriers after scene staging.
+//   * path state between the phases: {hit point, rbase} {direction, depth|branch|inst|refl} {weight, k1}
+//     as three float4 per slot; task state {cell sum, task id} {next sample | stack count}.  The <=3 pending
+//     transmitted children of the glass split (smallpt.cpp:252) live in a global-memory stack (rare).
+//   * RNG (D7), summation order (D9), sin/cos (D17), depth cap (D18), zero-weight cut (D19) and every
+//     arithmetic expression are those of spt_kernel.hip / the oracle: results are bit-identical.
+#include "spt_device.h"
+#include "spt_kernel.h"
+
+namespace spt {
+
+constexpr uint32_t kEpsBias = 0x38D1B717u + 1u;                  // bits(1e-4f) + 1
+constexpr uint32_t kInfKeyP = 0x60AD78ECu - kEpsBias;            // key of 1e20f
+constexpr int kPoolBlock = 256;
+constexpr uint32_t kNoTask = 0xFFFFFFFFu;
+constexpr int kStackWords = 12;                                  // o.xyz d.xyz w.xyz (depth|branch<<16) k0 k1
+constexpr int kMaxUnroll = 24;                                   // spheres handled by the unrolled closest-hit code
+
+__device__ __forceinline__ uint32_t lane_id_p() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t rank_in(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// packed word of a waiting path: [11:0] depth, [14:12] branch bits (D7), [15] weight-may-be-non-finite flag,
+// [27:16] sphere index, [29:28] Refl_t
+__device__ __forceinline__ uint32_t pack_path(uint32_t depth, uint32_t branchf, uint32_t inst, uint32_t refl)
+{
+    return depth | (branchf << 12) | (inst << 16) | (refl << 28);
+}
+
+enum { C_GEN = 0, C_DIFF = 1, C_REFR = 2 };
+
+template <int P, int NG>
+__global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
+{
+    static_assert(P % 64 == 0 || P == 96, "pool size");
+    extern __shared__ float4 lds[];
+    constexpr int kWaveF4 = (71 * P) / 16;                       // float4 per wave region (71 bytes per slot)
+    static_assert((71 * P) % 16 == 0, "wave region must be float4-aligned");
+    const uint32_t lane = lane_id_p();
+    const uint32_t wave = threadIdx.x >> 6;
+    float4* const A0 = lds + wave * kWaveF4;                     // {hx.xyz, rbase}
+    float4* const A1 = A0 + P;                                   // {d.xyz, packed}
+    float4* const A2 = A1 + P;                                   // {w.xyz, k1}
+    float4* const T0 = A2 + P;                                   // {cell sum xyz, task id}
+    uint32_t* const T1 = reinterpret_cast<uint32_t*>(T0 + P);    // next sample << 2 | pending stack entries
+    uint8_t* const LST = reinterpret_cast<uint8_t*>(T1 + P);     // 3 lists x P slot ids
+    float4* const s_geom = lds + (kPoolBlock / 64) * kWaveF4;    // n x {c.xyz, r*r}
+    float4* const s_mat = s_geom + 3 * NG;                       // 3 x (3 NG) material rows
+
+    for (uint32_t i = threadIdx.x; i < 3u * NG; i += kPoolBlock) {
+        const bool real = i < K.n;
+        s_geom[i] = real ? K.geom[i] : make_float4(0.f, 0.f, 0.f, -__builtin_inff());   // padding: never hit
+        s_mat[3 * i + 0] = real ? K.mat[3 * i + 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_mat[3 * i + 1] = real ? K.mat[3 * i + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_mat[3 * i + 2] = real ? K.mat[3 * i + 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // every slot starts on the GEN list as a finished, task-less slot
+    for (uint32_t s = lane; s < (uint32_t)P; s += 64) {
+        T0[s] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoTask));
+        T1[s] = K.samps << 2;
+        LST[C_GEN * P + s] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    const uint32_t wave_gid = blockIdx.x * (kPoolBlock / 64) + wave;
+    float* const gstack = K.stack + (size_t)wave_gid * (3 * kStackWords * P);
+    auto stack_at = [&](uint32_t e, int f, uint32_t slot) -> float& { return gstack[(e * kStackWords + f) * P + slot]; };
+
+    const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
+    const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
+    const f3 cam_cx = mk(K.cam_cx[0], K.cam_cx[1], K.cam_cx[2]);
+    const f3 cam_cy = mk(K.cam_cy[0], K.cam_cy[1], K.cam_cy[2]);
+
+    // wave-uniform state
+    uint32_t nG = (uint32_t)P, nD = 0u, nR = 0u;                 // list lengths
+    uint32_t chunk_next = 0, chunk_end = 0;                      // this wave's private range of task ids
+    bool queue_empty = false;
+    unsigned long long nbounce = 0;                              // closest-hit queries of this wave
+    uint32_t nkill = 0;                                          // per lane
+    uint32_t itG = 0, itD = 0, itR = 0;                          // batches per class (utilisation report)
+    unsigned long long lnG = 0, lnD = 0, lnR = 0;                // lanes per class
+    uint32_t itTail = 0, itFull = 0;                             // batches after the task queue ran dry / full batches
+    unsigned long long lnTail = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    uint32_t it_total = 0;
+    bool timed_out = false;
+
+    for (;;) {
+        // ---- choose the class of this batch: a full batch of the rarest class first, else the longest list ----
+        uint32_t c, b, lbase;
+        if (nR >= 64u) c = C_REFR;
+        else if (nG >= 64u) c = C_GEN;
+        else if (nD >= 64u) c = C_DIFF;
+        else {
+            c = C_DIFF;
+            uint32_t m = nD;
+            if (nG > m) { c = C_GEN; m = nG; }
+            if (nR > m) { c = C_REFR; m = nR; }
+            if (m == 0u) break;                                   // every list empty: all tasks of this wave are done
+        }
+        if (c == C_GEN) { b = nG < 64u ? nG : 64u; nG -= b; lbase = nG; ++itG; lnG += b; }
+        else if (c == C_DIFF) { b = nD < 64u ? nD : 64u; nD -= b; lbase = (uint32_t)P + nD; ++itD; lnD += b; }
+        else { b = nR < 64u ? nR : 64u; nR -= b; lbase = 2u * (uint32_t)P + nR; ++itR; lnR += b; }
+        if (queue_empty) { ++itTail; lnTail += b; }
+        if (b == 64u) ++itFull;
+        if ((++it_total & 255u) == 0u && K.watchdog_ticks != 0ull &&
+            __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
+
+        const bool valid = lane < b;
+        const uint32_t slot = valid ? (uint32_t)LST[lbase + lane] : 0u;
+
+        // per-lane path registers handed from the class code to the closest-hit query
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), w = mk(0, 0, 0);
+        uint32_t depth = 0, branchf = 0, rbase = 0, k1 = 0;
+        bool has_ray = false;
+        bool retired = false;                                    // GEN only: no task left for this slot
+
+        if (c == C_GEN) {
+            // ================= GEN: continue the slot's task (smallpt.cpp:304-340, :252 pop) =================
+            const float4 t0 = T0[slot];
+            const uint32_t t1 = T1[slot];
+            uint32_t snext = t1 >> 2, sp = t1 & 3u;
+            uint32_t task = __float_as_uint(t0.w);
+            bool gen = false;
+            bool need_task = false;
+            if (valid) {
+                if (sp > 0u) {                                   // pending transmitted child (reflected subtree is done)
+                    --sp;
+                    o = mk(stack_at(sp, 0, slot), stack_at(sp, 1, slot), stack_at(sp, 2, slot));
+                    d = mk(stack_at(sp, 3, slot), stack_at(sp, 4, slot), stack_at(sp, 5, slot));
+                    w = mk(stack_at(sp, 6, slot), stack_at(sp, 7, slot), stack_at(sp, 8, slot));
+                    const uint32_t db = __float_as_uint(stack_at(sp, 9, slot));
+                    depth = db & 0xFFFu; branchf = db >> 16;
+                    const uint32_t k0 = __float_as_uint(stack_at(sp, 10, slot));
+                    k1 = __float_as_uint(stack_at(sp, 11, slot));
+                    rbase = rng_base(k0, branchf & 7u, depth);
+                    T1[slot] = (snext << 2) | sp;
+                    has_ray = true;
+                } else if (snext == K.samps) {
+                    need_task = true;                            // cell finished (or the slot never had a task)
+                } else {
+                    gen = true;
+                }
+            }
+            const unsigned long long need_mask = __ballot(need_task);
+            if (need_mask != 0ull) {
+                if (need_task && task != kNoTask) K.cells[task] = make_float4(t0.x, t0.y, t0.z, 0.0f);
+                // wave-private chunks of task ids; only the refill touches the global queue word
+                const uint32_t cntn = (uint32_t)__popcll(need_mask);
+                const uint32_t rk = rank_in(need_mask);
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t base_old = chunk_next;
+                uint32_t base_new = 0;
+                if (cntn > avail) {
+                    if (!queue_empty) {
+                        const int leader = __ffsll((long long)need_mask) - 1;
+                        uint32_t nb = 0;
+                        if ((int)lane == leader) nb = atomicAdd(K.queue, 64u);
+                        base_new = uni(__shfl(nb, leader));
+                        if (base_new >= K.ntasks) queue_empty = true;
+                    } else {
+                        base_new = K.ntasks;                     // nothing left: ids >= ntasks mean "no task"
+                    }
+                    chunk_next = base_new + (cntn - avail);
+                    chunk_end = base_new + 64u;
+                    if (queue_empty) { chunk_next = chunk_end = 0; }
+                } else {
+                    chunk_next += cntn;
+                }
+                if (need_task) {
+                    const uint32_t nt = rk < avail ? base_old + rk : base_new + (rk - avail);
+                    if (nt < K.ntasks) {
+                        task = nt; snext = 0; gen = true;
+                        T0[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(task));
+                    } else {
+                        retired = true;                          // the slot is pushed onto no list
+                    }
+                }
+            }
+            if (gen) {
+                // ---- camera ray of sample `snext` of the cell (smallpt.cpp:325-340 / :745-760) ----
+                const uint32_t pix_local = task >> 2, cell = task & 3u;
+                const uint32_t ry = pix_local / K.w;
+                const uint32_t px = pix_local - ry * K.w;
+                const uint32_t py = K.row_begin + ry;
+                const uint32_t pixel_idx = py * K.w + px;                    // GLOBAL index (:298)
+                const uint32_t p0 = mix32(pixel_idx + K.s0);
+                const uint32_t p1 = mix32(pixel_idx ^ K.s1);
+                const uint32_t index_in_pixel = cell * K.samps + snext;      // :306
+                const uint32_t k0 = mix32(p0 ^ (index_in_pixel * kGolden));
+                k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
+                const float u1 = rng_draw(k0 + ((1u << 28) | 0u) * kGolden, k1);
+                const float u2 = rng_draw(k0 + ((1u << 28) | 1u) * kGolden, k1);
+                const uint32_t sx = cell & 1u, sy = cell >> 1;
+                float ax, ay;
+                if (K.sampler == 0u) {
+                    const float r1 = 2 * u1;                                  // tent filter :327-330
+                    const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
+                    const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
+                    const float r2 = 2 * u2;
+                    const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
+                    const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
+                    // :331-332 in double like the reference; a / w as the exact Markstein sequence (tools/verify_exact_math.c)
+                    const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
+                    const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
+                    const double qx0 = tx * K.inv_w, qy0 = ty * K.inv_h;
+                    const double qx = __builtin_fma(__builtin_fma(-qx0, (double)K.w, tx), K.inv_w, qx0);
+                    const double qy = __builtin_fma(__builtin_fma(-qy0, (double)K.h, ty), K.inv_h, qy0);
+                    ax = (float)(qx - .5); ay = (float)(qy - .5);
+                } else {
+                    const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;      // :750
+                    const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);              // :753-758
+                    const float nx = (((float)px + 0.5f) + fx) * K.inv_wf;                       // :628-631
+                    const float ny = (((float)py + 0.5f) + fy) * K.inv_hf;
+                    ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;                                    // :633
+                }
+                const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
+                const float inv = rcp_exact(sqrt_exact(dot(dd, dd)));
+                o = cam_o + dd * K.cam_push;                                                    // :333
+                d = dd * inv;                                                                   // normalize(d)
+                w = mk(1, 1, 1); depth = 0; branchf = 0; rbase = k0;                             // :338-339
+                T1[slot] = (snext + 1u) << 2;
+                has_ray = true;
+            }
+        } else {
+            // ================= DIFF / REFR: shade the waiting hit (smallpt.cpp:170-263) =================
+            const float4 a0 = A0[slot], a1 = A1[slot], a2 = A2[slot];
+            const f3 hx = mk(a0.x, a0.y, a0.z);
+            rbase = __float_as_uint(a0.w);
+            const f3 din = mk(a1.x, a1.y, a1.z);
+            const uint32_t pk = valid ? __float_as_uint(a1.w) : 0u;       // idle lanes: sphere 0, never stored
+            w = mk(a2.x, a2.y, a2.z);
+            k1 = __float_as_uint(a2.w);
+            depth = pk & 0xFFFu; branchf = (pk >> 12) & 0xFu;
+            const uint32_t inst = (pk >> 16) & 0xFFFu;
+            const float4 gh = s_geom[inst];
+            const f3 n = normalize<false>(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));       // scene.cpp:124
+            const f3 nl = dot(n, din) < 0 ? n : neg(n);                                     // :174 (D2)
+            if (c == C_DIFF) {
+                const bool is_diff = ((pk >> 28) & 3u) == 0u;
+                o = hx + nl * 0.02f;                                                        // :172 (D3)
+                if (is_diff) {                                                              // DIFF :208-215
+                    const uint32_t u1bits = rng_draw_bits(rbase + kGolden, k1);
+                    const float r2 = rng_draw(rbase + 2u * kGolden, k1);
+                    const float r2s = sqrt_fix_int(r2);
+                    float sn, cs;
+                    sincos2pi_bits(u1bits, sn, cs);                                          // D17
+                    const f3 ww = nl;
+                    const bool ay = __builtin_fabsf(ww.x) >= 0.1f;                          // (double)fabs(w.x) > .1, :211
+                    const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
+                    const float s2 = ay ? ww.x : ww.y;
+                    const float qu = ww.z * ww.z + s2 * s2;
+                    const f3 uu = ur * rcp_exact<false>(sqrt_fix_int(qu));
+                    const f3 vv = cross(ww, uu);
+                    d = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix_int(1 - r2));   // :212
+                } else {
+                    d = din - n * 2.0f * dot(n, din);                                       // SPEC :218-223
+                }
+                // the weight was multiplied, the depth cap and the zero-weight cut applied before the slot was queued
+                ++depth;
+                rbase += 4u * kGolden;
+                has_ray = valid;
+            } else {
+                // ---- glass, smallpt.cpp:225-263 ----
+                const float4 mfc = s_mat[3 * inst + (depth > 5u ? 2 : 1)];                  // f after the roulette (:192)
+                const f3 f = mk(mfc.x, mfc.y, mfc.z);
+                const f3 off = nl * 0.02f;                                                  // :172 (D3)
+                f3 no = hx + off, nf = f;
+                f3 nd = din - n * 2.0f * dot(n, din);                                       // :218 reflRay
+                const bool into = dot(n, nl) > 0;                                           // :225
+                const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;                         // :228
+                const float ddn = dot(din, nl);                                             // :229
+                const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);                        // :230
+                if (valid && !(cos2t < 0)) {                                                // else TIR :232-236
+                    const f3 tdir = normalize<true>(din * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t)))); // :238
+                    const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);                         // :240-242
+                    const float cc = 1 - (into ? -ddn : dot(tdir, n));                      // :243
+                    const float c2 = cc * cc;                                               // :244
+                    const float Re = R0 + (1 - R0) * c2 * c2 * cc;                          // :245
+                    const float Tr = 1 - Re;                                                // :246
+                    const f3 xin = hx - off;                                                // D3
+                    if (depth <= 2u) {                                                      // :248 split (D6)
+                        const f3 tw = w * (f * Tr);
+                        if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
+                            const uint32_t t1 = T1[slot];
+                            const uint32_t sp = t1 & 3u;
+                            const uint32_t br = branchf & 7u;
+                            const bool nonfin = !(__builtin_fabsf(tw.x) < __builtin_inff() && __builtin_fabsf(tw.y) < __builtin_inff() && __builtin_fabsf(tw.z) < __builtin_inff());
+                            stack_at(sp, 0, slot) = xin.x; stack_at(sp, 1, slot) = xin.y; stack_at(sp, 2, slot) = xin.z;
+                            stack_at(sp, 3, slot) = tdir.x; stack_at(sp, 4, slot) = tdir.y; stack_at(sp, 5, slot) = tdir.z;
+                            stack_at(sp, 6, slot) = tw.x; stack_at(sp, 7, slot) = tw.y; stack_at(sp, 8, slot) = tw.z;
+                            stack_at(sp, 9, slot) = __uint_as_float((depth + 1u) | ((br | (1u << depth) | ((branchf & 8u) | (nonfin ? 8u : 0u))) << 16));
+                            stack_at(sp, 10, slot) = __uint_as_float(rbase - ((br << 29) | (depth << 2)) * kGolden);   // k0
+                            stack_at(sp, 11, slot) = __uint_as_float(k1);
+                            T1[slot] = t1 + 1u;
+                        }
+                        nf = f * Re;
+                    } else {
+                        const float Pr = 0.25f + 0.5f * Re;                                 // :256
+                        const bool pick_refl = rng_draw(rbase + kGolden, k1) < Pr;          // :257
+                        const float inv = rcp_exact(pick_refl ? Pr : 1.f - Pr);             // :259 / :263
+                        nf = f * (pick_refl ? Re : Tr) * inv;
+                        if (!pick_refl) { no = xin; nd = tdir; }
+                    }
+                }
+                // extend() smallpt.cpp:120-123 + D18 + D19
+                w = w * nf;
+                o = no; d = nd;
+                ++depth;
+                rbase += 4u * kGolden;
+                if (valid) {
+                    if (depth >= SPT_K_MAX_DEPTH) ++nkill;
+                    else if (!(w.x == 0.f && w.y == 0.f && w.z == 0.f)) has_ray = true;
+                    if (!(__builtin_fabsf(w.x) < __builtin_inff() && __builtin_fabsf(w.y) < __builtin_inff() && __builtin_fabsf(w.z) < __builtin_inff())) branchf |= 8u;
+                }
+            }
+        }
+
+        // ================= closest hit, smallpt.cpp:54-70 over scene.cpp:129-140 (D1, D16) =================
+        // Selection on integer keys key(t) = bits(t) - (bits(eps) + 1): "t > eps && t < nearest" is one unsigned
+        // compare; det < 0 gives NaN keys that never win (see spt_kernel.hip phase D1).  The table is padded by the host
+        // to 3 * NG spheres with never-hit entries (r*r = -inf: det = -inf, NaN keys), so the loop is fully unrolled
+        // without bounds tests; ascending index with strict '<' = lowest index wins ties.
+        nbounce += (unsigned long long)__popcll(__ballot(has_ray));
+        uint32_t next = C_GEN;                                   // slots without a continuing path go back to GEN
+        const bool queued = valid && !retired;
+        if (has_ray) {
+            uint32_t near_key = kInfKeyP;
+            uint32_t inst = 0;
+#define SPT_PSPH(i)                                                                         \
+            if ((i) < 3 * NG) {                                                             \
+                const float4 g = s_geom[(i)];                                               \
+                const f3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);                          /* :132 */ \
+                const float bb = dot(op, d);                                                /* :133 */ \
+                const float det = bb * bb - dot(op, op) + g.w;                              /* :133 (g.w = r*r) */ \
+                const float sd = sqrt_fix_int(det);                                         /* :134 */ \
+                const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;                  /* :135 */ \
+                const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;                  \
+                const uint32_t kmin = key1 < key2 ? key1 : key2;                            \
+                const uint32_t nn = kmin < near_key ? kmin : near_key;                      \
+                if (nn != near_key) inst = (i);                                             /* :61 strict <: lowest index wins ties */ \
+                near_key = nn;                                                              \
+            }
+            SPT_PSPH(0) SPT_PSPH(1) SPT_PSPH(2) SPT_PSPH(3) SPT_PSPH(4) SPT_PSPH(5) SPT_PSPH(6) SPT_PSPH(7)
+            SPT_PSPH(8) SPT_PSPH(9) SPT_PSPH(10) SPT_PSPH(11) SPT_PSPH(12) SPT_PSPH(13) SPT_PSPH(14) SPT_PSPH(15)
+            SPT_PSPH(16) SPT_PSPH(17) SPT_PSPH(18) SPT_PSPH(19) SPT_PSPH(20) SPT_PSPH(21) SPT_PSPH(22) SPT_PSPH(23)
+#undef SPT_PSPH
+            // ---- class-independent part of shadePaths (smallpt.cpp:168-198) ----
+            if (near_key != kInfKeyP) {                                                     // else :168 miss (D13)
+                const float t = __uint_as_float(near_key + kEpsBias);
+                const float4 me = s_mat[3 * inst + 0];                                      // emission.xyz, refl | emissive << 2
+                const float4 mc = s_mat[3 * inst + 1];                                      // color.xyz, pmax
+                const uint32_t rb = __float_as_uint(me.w);
+                const uint32_t refl = rb & 3u;
+                if ((rb & 4u) != 0u || (branchf & 8u) != 0u) {                              // :179 (D4); + w*0 is skipped, exact for finite w
+                    float4 acc = T0[slot];
+                    acc.x = acc.x + w.x * me.x; acc.y = acc.y + w.y * me.y; acc.z = acc.z + w.z * me.z;
+                    T0[slot] = acc;
+                }
+                f3 f = mk(mc.x, mc.y, mc.z);                                                // :175
+                bool cont = true;
+                if (depth > 5u) {                                                           // :188 (D5)
+                    if (rng_draw(rbase, k1) < mc.w) {
+                        const float4 mf = s_mat[3 * inst + 2];                              // color * (1/pmax), :192
+                        f = mk(mf.x, mf.y, mf.z);
+                    } else {
+                        cont = false;                                                       // :196
+                    }
+                }
+                if (cont) {
+                    if (refl != 2u) {
+                        // extend() of the DIFF / SPEC child (:214,:221): weight, D18 depth cap, D19 zero-weight cut
+                        w = w * f;
+                        if (depth + 1u >= SPT_K_MAX_DEPTH) { ++nkill; cont = false; }
+                        else if (w.x == 0.f && w.y == 0.f && w.z == 0.f) cont = false;
+                    }
+                    if (cont) {
+                        const f3 hx = o + d * t;                                            // scene.cpp:137
+                        A0[slot] = make_float4(hx.x, hx.y, hx.z, __uint_as_float(rbase));
+                        A1[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(pack_path(depth, branchf, inst, refl)));
+                        A2[slot] = make_float4(w.x, w.y, w.z, __uint_as_float(k1));
+                        next = refl == 2u ? C_REFR : C_DIFF;
+                    }
+                }
+            }
+        }
+        // ================= push every slot onto the list of its next class =================
+        {
+            const unsigned long long mg = __ballot(queued && next == C_GEN);
+            const unsigned long long md = __ballot(queued && next == C_DIFF);
+            const unsigned long long mr = __ballot(queued && next == C_REFR);
+            uint32_t pos = nG + rank_in(mg);
+            if (next == C_DIFF) pos = (uint32_t)P + nD + rank_in(md);
+            if (next == C_REFR) pos = 2u * (uint32_t)P + nR + rank_in(mr);
+            if (queued) LST[pos] = (uint8_t)slot;
+            nG += (uint32_t)__popcll(mg);
+            nD += (uint32_t)__popcll(md);
+            nR += (uint32_t)__popcll(mr);
+        }
+    }
+
+    // stats: one atomic per wave
+    unsigned long long nk = nkill;
+    for (int off = 32; off > 0; off >>= 1) nk += __shfl_down(nk, off);
+    if (lane == 0) {
+        atomicAdd(&K.counters[0], nbounce);
+        if (nk) atomicAdd(&K.counters[1], nk);
+        atomicAdd(&K.counters[2], (unsigned long long)itG); atomicAdd(&K.counters[3], (unsigned long long)itD);
+        atomicAdd(&K.counters[4], (unsigned long long)itR);
+        atomicAdd(&K.counters[5], lnG); atomicAdd(&K.counters[6], lnD); atomicAdd(&K.counters[7], lnR);
+        if (timed_out) atomicAdd(&K.counters[8], 1ull);
+        atomicAdd(&K.counters[9], (unsigned long long)itTail); atomicAdd(&K.counters[10], lnTail);
+        atomicAdd(&K.counters[11], (unsigned long long)itFull);
+    }
+}
+
+}  // namespace spt
+
+// LDS per 256-thread workgroup: four wave pools + the padded scene table (16 B geometry + 48 B material per sphere)
+extern "C" size_t spt_pool_lds_bytes(uint32_t n, int pool)
+{
+    const uint32_t ng = n == 0 ? 1u : (n + 2u) / 3u;
+    return (size_t)(spt::kPoolBlock / 64) * 71u * (size_t)pool + (size_t)ng * 3u * 64u;
+}
+
+extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool)
+{
+    return (size_t)blocks * (spt::kPoolBlock / 64) * 3u * spt::kStackWords * (size_t)pool;
+}
+
+extern "C" int spt_pool_max_spheres(void) { return spt::kMaxUnroll; }
+
+template <int P, int NG>
+static hipError_t launch_pool(const spt::KParams* K, uint32_t blocks, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::poolkernel<P, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((spt::poolkernel<P, NG>), dim3(blocks), dim3(spt::kPoolBlock), lds, stream, *K);
+    return hipGetLastError();
+}
+
+template <int P>
+static hipError_t launch_pool_ng(const spt::KParams* K, uint32_t blocks, size_t lds, hipStream_t stream)
+{
+    switch (K->n == 0 ? 1u : (K->n + 2u) / 3u) {
+    case 1: return launch_pool<P, 1>(K, blocks, lds, stream);
+    case 2: return launch_pool<P, 2>(K, blocks, lds, stream);
+    case 3: return launch_pool<P, 3>(K, blocks, lds, stream);
+    case 4: return launch_pool<P, 4>(K, blocks, lds, stream);
+    case 5: return launch_pool<P, 5>(K, blocks, lds, stream);
+    case 6: return launch_pool<P, 6>(K, blocks, lds, stream);
+    case 7: return launch_pool<P, 7>(K, blocks, lds, stream);
+    case 8: return launch_pool<P, 8>(K, blocks, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, int pool, hipStream_t stream)
+{
+    const size_t lds = spt_pool_lds_bytes(K->n, pool);
+    if (pool == 128) return launch_pool_ng<128>(K, blocks, lds, stream);
+#ifdef SPT_POOL_SIZES
+    if (pool == 96) return launch_pool_ng<96>(K, blocks, lds, stream);
+    if (pool == 192) return launch_pool_ng<192>(K, blocks, lds, stream);
+#endif
+    return hipErrorInvalidValue;
+}

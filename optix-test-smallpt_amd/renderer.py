@@ -122,6 +122,14 @@ class Renderer:
             FLAG_NORMALISE if normalise else 0, C.c_void_p(out_tensor.data_ptr()),
             C.c_void_p(stream) if stream else None))
 
+    def set_watchdog(self, seconds):
+        """Pool kernel: a launch whose waves run longer than this fails in sync() instead of hanging (0 = off)."""
+        self._check(self._lib.spt_set_watchdog(self._h, float(seconds)))
+
+    def last_kernel(self):
+        """'pool' (spt_pool.hip, material-sorted) or 'mega' (spt_kernel.hip) for the last launch."""
+        return "pool" if self._lib.spt_last_kernel(self._h) == 1 else "mega"
+
     def diag(self):
         """Phase timings / lane counters of the last launch of the instrumented build (variant bit 8)."""
         arr = (C.c_uint64 * 15)()
@@ -147,7 +155,8 @@ class ProgressiveRenderer:
     every ``step()`` renders one frame with seed = frame counter (:893,922,926) as an un-normalised sum
     (Renderer::render convention), adds it to the accumulation tensor (:935) and returns the display weight
     1/(frames*spp) of :957.  ``update_camera`` mirrors the "update_camera" request (:911-916): new camera,
-    buffer cleared on the next frame, counter restarted."""
+    the next frame is still rendered with the RUNNING frame counter as its seed (:922), replaces the buffer
+    (:931-935), and only then is the counter reset to 1 (:938-939)."""
 
     def __init__(self, renderer, w, h, samps_per_cell, camera=None):
         import torch
@@ -156,8 +165,8 @@ class ProgressiveRenderer:
         dev = torch.device("cuda", renderer.device_id)
         self.accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
         self.frame = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
-        self.frames = 0
-        self._clear = True
+        self.frames = 0          # sampleCount, smallpt.cpp:893
+        self._clear = True       # the zero-initialised accumBuffer (:882): replacing it == adding to zeros
 
     def update_camera(self, camera):
         self.camera = camera
@@ -166,7 +175,7 @@ class ProgressiveRenderer:
     def step(self):
         import torch
         stream = torch.cuda.current_stream().cuda_stream
-        seed = 0 if self._clear else self.frames       # sampleCount restarts at 1 after a clear (:938-939)
+        seed = self.frames       # :922 renders with the running sampleCount, also on the clearing frame
         self.r.render_rows_device(self.frame, self.w, self.h, 0, self.h, self.samps, seed=seed, normalise=False,
                                   camera=self.camera, stream=stream)
         self.r._check(self.r._lib.spt_accumulate_device(self.r._h, C.c_void_p(self.accum.data_ptr()),

@@ -29,5 +29,6 @@ def pkg():
 @pytest.fixture(scope="session")
 def renderer(pkg):
     r = pkg.Renderer(0)
+    r.set_watchdog(60.0)       # a scheduling bug in the persistent kernels must fail a test, not hang the GPU box
     yield r
     r.close()

@@ -12,8 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "smallpt_mi355x.h")
 
 
-def _declared_symbols():
-    text = open(HEADER).read()
+INTERNAL_HEADER = os.path.join(ROOT, "optix-test-smallpt_amd", "csrc", "spt_internal.h")
+
+
+def _declared_symbols(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(spt_[a-z_0-9]+)\s*\(", text)))
 
@@ -25,6 +28,11 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/smallpt_mi355x.h but not exported"
     assert sorted(pkg.SYMBOLS) == declared          # the Python binding covers the whole header
+    # test/tuning hooks live in an internal header, not in the drop-in boundary
+    internal = _declared_symbols(INTERNAL_HEADER)
+    assert sorted(pkg.INTERNAL_SYMBOLS) == internal and not set(internal) & set(declared)
+    for name in internal:
+        assert hasattr(lib, name)
     assert lib.spt_api_version() == 1
 
 

@@ -18,7 +18,7 @@ i=0
 NP=${SPT_PMC_PASSES:-${#PASSES[@]}}
 for P in "${PASSES[@]}"; do
   [ $i -ge $NP ] && break
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $R/gpurun_out/${TAG}_p$i.log; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/${TAG}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $R/gpurun_out/${TAG}_p$i.log; }
   i=$((i+1))
 done
 python3 - "$R" "$TAG" <<'PY'
