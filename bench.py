@@ -177,6 +177,7 @@ def main():
         fl = flops_per_sample(bbar, N_SPHERES)
         achieved = my_samples * fl / k_s / 1e12
         f_s = (sum(fms) / len(fms)) * 1e-3
+        nb = 8 if samps >= 128 else (4 if samps >= 64 else (2 if samps >= 32 else 1))   # D9 sample blocks per jitter cell
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
@@ -201,7 +202,8 @@ def main():
                                  "flops per SURVEY.md 8(d); arithmetic is non-contracted IEEE mul/add (1 flop/instr) "
                                  "for bit-parity with the reference's host arithmetic, so frac <= 0.5 by construction",
                          "hbm_store_kernel": {"kernel": "spt::finalize", "ms": round(f_s * 1e3, 4),
-                                              "achieved_GBps": round(count * W * (64 + 12) / f_s / 1e9, 1),
+                                              "achieved_GBps": round(count * W * (64 * nb + 12) / f_s / 1e9, 1),
+                                              "bytes_per_pixel": 64 * nb + 12,
                                               "peak_GBps": HBM_PEAK_GBPS}},
         }
         if world == 1 and not args.no_extras:

@@ -264,12 +264,15 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     if (row_count == 0 || (uint64_t)row_begin + row_count > h) return c->fail("spt_render_rows_device: row band [%u,+%u) outside image height %u", row_begin, row_count, h);
     if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: spp overflows 32 bits");
     const uint64_t npix = (uint64_t)row_count * w;
-    if (npix * 4 > 0xF0000000ull) return c->fail("spt_render_rows_device: band has more than 15*2^26 pixels; split it");
+    // D9: a jitter cell's samples are accumulated in nb = 1, 2, 4 or 8 blocks (>= 16 samples each); one task = one block
+    const uint32_t nb_log2 = samps >= 128u ? 3u : (samps >= 64u ? 2u : (samps >= 32u ? 1u : 0u));
+    const uint32_t nb = 1u << nb_log2;
+    if (npix * 4 * nb > 0xF0000000ull) return c->fail("spt_render_rows_device: band has more than 15*2^26 sample blocks (%u per pixel); split it", 4u * nb);
     if (!c->d_geom) return c->fail("spt_render_rows_device: no scene set (call spt_set_scene)");
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) { SPT_HIP(c, hipEventSynchronize(c->ev_stop)); }
 
-    const size_t ntasks = (size_t)npix * 4;
+    const size_t ntasks = (size_t)npix * 4 * nb;
     if (ntasks > c->cells_cap) {
         if (c->d_cells) (void)hipFree(c->d_cells);
         c->d_cells = nullptr; c->cells_cap = 0;
@@ -287,6 +290,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     P.w = w; P.h = h; P.row_begin = row_begin; P.row_count = row_count;
     P.inv_w = 1.0 / (double)w; P.inv_h = 1.0 / (double)h;
     P.samps = samps; P.ntasks = (uint32_t)ntasks;
+    P.nb_log2 = nb_log2; P.sb = (samps + nb - 1u) / nb;
     P.park_threshold = (c->variant & 0xFFu) ? (c->variant & 0xFFu) : 8u;
     P.s0 = mix32((uint32_t)seed + 0x243F6A88u);
     P.s1 = mix32((uint32_t)(seed >> 32) ^ P.s0 ^ 0x85A308D3u);
@@ -302,7 +306,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     // ---- material-sorted pool kernel (spt_pool.hip): small tables, regular scenes; variant bit 10 forces the megakernel ----
     if (c->pool_ok && cam_big <= 1e15f && !(c->variant & 0x500u)) {
         const uint32_t psel = (c->variant >> 11) & 3u;
-        const int pool = psel == 1 ? 96 : (psel == 2 ? 192 : 128);
+        const int pool = psel == 1 ? 96 : (psel == 2 ? 192 : (psel == 3 ? 128 : 160));   // default 160: four workgroups per CU, batches ~98 % full
         const size_t lds = spt_pool_lds_bytes(P.n, pool);
         uint32_t per_cu = c->blocks_per_cu;
         if (per_cu == 0) {
@@ -313,7 +317,9 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
         const uint64_t needed = (ntasks + 255) / 256;
         if (blocks > needed) blocks = needed;
         if (blocks < 1) blocks = 1;
-        const size_t need_stack = spt_pool_stack_floats((uint32_t)blocks, pool);
+        // one allocation: the children stack followed by the {task, next sample} words of every slot
+        const size_t stack_floats = spt_pool_stack_floats((uint32_t)blocks, pool);
+        const size_t need_stack = stack_floats + spt_pool_state_bytes((uint32_t)blocks, pool) / sizeof(float);
         if (need_stack > c->stack_cap) {
             if (c->d_stack) (void)hipFree(c->d_stack);
             c->d_stack = nullptr; c->stack_cap = 0;
@@ -321,12 +327,13 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
             c->stack_cap = need_stack;
         }
         P.stack = c->d_stack;
+        P.slot_state = reinterpret_cast<uint2*>(c->d_stack + stack_floats);
         P.watchdog_ticks = c->watchdog_ticks;
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));
         SPT_HIP(c, spt_pool_launch(&P, (uint32_t)blocks, pool, st));
         SPT_HIP(c, hipEventRecord(c->ev_mid, st));
-        SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
+        SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
         c->pending = true;
         c->last_was_pool = true;
@@ -357,7 +364,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
     SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, (c->needs_guard || !(cam_big <= 1e15f)) ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, (c->n > 24u) ? 1 : 0, big_block, st));
     SPT_HIP(c, hipEventRecord(c->ev_mid, st));
-    SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, st));
+    SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
     SPT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->pending = true;
     c->last = spt_stats{};

@@ -15,7 +15,7 @@ extern "C" {
 /* Tuning knobs (0 = default).  blocks_per_cu caps the persistent grid; variant bits 0..7 = number of
  * waiting lanes that triggers a wave's glass-shading pass (0 = default 8), bit 8 = instrumented kernel
  * build (see spt_diag), bit 9 = 512-thread workgroups for tables above 256 spheres, bit 10 = force the megakernel where the pool kernel
- * would run, bits 12:11 = pool slots per wave (0: 128, 1: 96, 2: 192).  Results never depend on these. */
+ * would run, bits 12:11 = pool slots per wave (0: 160, 3: 128; 1: 96 and 2: 192 in -DSPT_POOL_SIZES builds).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
 /* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
  * out15[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters. */

@@ -17,7 +17,8 @@ struct KParams {
     uint32_t w, h, row_begin, row_count;
     double inv_w, inv_h;     // RN(1/w), RN(1/h) for the exact double division of smallpt.cpp:331-332
     uint32_t samps;          // samples per jitter cell (spp = 4*samps)
-    uint32_t ntasks;         // 4 * row_count * w
+    uint32_t ntasks;         // 4 * row_count * w * nb: one task = one block of a jitter cell's samples (D9)
+    uint32_t nb_log2, sb;    // nb = 1 << nb_log2 blocks per cell, sb samples per block (last block may be shorter)
     uint32_t park_threshold; // glass-shading pass runs when this many lanes of a wave wait for it
     // RNG seed hashes (D7), computed on the host once per render
     uint32_t s0, s1;
@@ -26,12 +27,13 @@ struct KParams {
     const float4* geom;      // n x {cx, cy, cz, r*r}
     const float4* mat;       // n x 3: {e.xyz, refl bits}, {color.xyz, pmax}, {color*(1/pmax), 0}
     // outputs
-    float4* cells;           // ntasks cell sums
+    float4* cells;           // ntasks block sums
     uint32_t* queue;         // task queue head (zeroed before launch)
     unsigned long long* counters;  // [0] bounces, [1] depth-cap kills, [2..16] DIAG phase times / lane counts
                                    // pool kernel: [2..4] batches per class (GEN, DIFF, REFR), [5..7] lanes per class, [8] watchdog hits
     // pool kernel (spt_pool.hip) only
     float* stack;                  // pending transmitted children: waves x 3 entries x 12 words x pool slots
+    uint2* slot_state;             // waves x pool slots x {task id, next sample}
     unsigned long long watchdog_ticks;  // s_memtime ticks after which a wave gives up (0 = never)
 };
 
@@ -39,12 +41,13 @@ struct KParams {
 
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block);
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream);
-extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream);
+extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream);
 extern "C" int spt_k_block_threads(void);
 extern "C" int spt_k_block_threads_for(int mat_lds, int big_block);
 extern "C" hipError_t spt_k_selftest(int op, const float* d_in, float* d_out, uint32_t n, uint32_t w, hipStream_t stream);
 extern "C" size_t spt_pool_lds_bytes(uint32_t n, int pool);
 extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool);
+extern "C" size_t spt_pool_state_bytes(uint32_t blocks, int pool);
 extern "C" int spt_pool_max_spheres(void);
 extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, int pool, hipStream_t stream);
 extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream);

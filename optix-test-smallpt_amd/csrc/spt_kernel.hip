@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
     bool parked = false;         // hit a REFR sphere; waits for the wave's next glass-shading pass
     bool task_valid = false, queue_empty = false;
     uint32_t task = 0, sp = 0;
-    uint32_t s_gen = P.samps;    // next sample of the task to generate a camera ray for
+    uint32_t s_gen = 0, s_end = 0;   // next sample of the task to generate a camera ray for / end of the task's sample block (D9)
     uint32_t rcount = 0;         // camera rays ready in the two-entry register queue (ra = oldest)
     CamRay ra{mk(0, 0, 0), 0.f, 0u, 0u}, rb{mk(0, 0, 0), 0.f, 0u, 0u};
     uint32_t px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
         }
         SPT_STAMP(0)
         // ---- phase B: task completion + wave-aggregated fetch from the global queue ----
-        const bool need_task = !alive && rcount == 0 && s_gen == P.samps && !queue_empty;   // sp == 0 here
+        const bool need_task = !alive && rcount == 0 && s_gen == s_end && !queue_empty;   // sp == 0 here
         const unsigned long long need_mask = __ballot(need_task);
         if (need_mask != 0ull) {
             if (need_task && task_valid) P.cells[task] = make_float4(acc.x, acc.y, acc.z, 0.0f);
@@ -175,15 +175,19 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                 task = base + rank;
                 task_valid = task < P.ntasks;
                 if (task_valid) {
-                    const uint32_t pix_local = task >> 2;
-                    cell = task & 3u;
+                    // task = ((pixel * 4 + cell) << nb_log2) | block: one block of a jitter cell's samples (D9)
+                    const uint32_t cellid = task >> P.nb_log2;
+                    const uint32_t blk = task & ((1u << P.nb_log2) - 1u);
+                    const uint32_t pix_local = cellid >> 2;
+                    cell = cellid & 3u;
                     const uint32_t ry = pix_local / P.w;
                     px = pix_local - ry * P.w;
                     py = P.row_begin + ry;
                     const uint32_t pixel_idx = py * P.w + px;          // GLOBAL index (smallpt.cpp:298)
                     p0 = mix32(pixel_idx + P.s0);
                     p1 = mix32(pixel_idx ^ P.s1);
-                    s_gen = 0;
+                    s_gen = blk * P.sb;
+                    s_end = s_gen + P.sb < P.samps ? s_gen + P.sb : P.samps;
                     acc = mk(0, 0, 0);
                 } else {
                     queue_empty = true;
@@ -194,10 +198,10 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
         // ---- phase C1: batched path regeneration (smallpt.cpp:325-340).  Runs only when some lane is out
         // of camera rays; then EVERY lane with a free queue slot generates one, so the ~130-instruction
         // generator executes with most lanes active instead of once per terminated path. ----
-        const bool starved = !alive && rcount == 0 && task_valid && s_gen < P.samps;
+        const bool starved = !alive && rcount == 0 && task_valid && s_gen < s_end;
         if (__ballot(starved) != 0ull) {
-            if (DIAG) { ++runs_c1; lanes_c1 += __popcll(__ballot(task_valid && s_gen < P.samps && rcount < 2u)); }
-            if (task_valid && s_gen < P.samps && rcount < 2u) {
+            if (DIAG) { ++runs_c1; lanes_c1 += __popcll(__ballot(task_valid && s_gen < s_end && rcount < 2u)); }
+            if (task_valid && s_gen < s_end && rcount < 2u) {
                 if (nbounce > 0x40000000u) {           // keep the 32-bit per-lane counter from wrapping at extreme spp
                     atomicAdd(&P.counters[0], (unsigned long long)nbounce);
                     nbounce = 0;
@@ -474,23 +478,33 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
     }
 }
 
-// D9: pixel = ((c0 + c1) + c2) + c3, optional * (1/spp) (smallpt.cpp:358-361).  One lane per pixel: 64 B of
-// contiguous cell sums in, 12 B out.  The packed float3 rows are written with coalesced 16-byte stores: the
-// workgroup's 256 pixels (3 KB) are transposed through LDS and stored as 192 float4 (ALIGNED16 build; the
-// scalar build serves output pointers that are not 16-byte aligned).  HBM-bound: 76 B per pixel.
+// D9: cell = ((B0 + B1) + B2) + ... over its nb block sums, pixel = ((c0 + c1) + c2) + c3, optional * (1/spp)
+// (smallpt.cpp:358-361).  One lane per pixel: 4 * nb contiguous float4 block sums in, 12 B out.  The packed float3 rows
+// are written with coalesced 16-byte stores: the workgroup's 256 pixels (3 KB) are transposed through LDS and stored as
+// 192 float4 (ALIGNED16 build; the scalar build serves output pointers that are not 16-byte aligned).  HBM-bound.
 template <bool ALIGNED16>
 __global__ __launch_bounds__(kBlock) void finalize(const float4* __restrict__ cells, float* __restrict__ out,
-                                                   uint32_t npix, float scale, int normalise)
+                                                   uint32_t npix, float scale, int normalise, uint32_t nb)
 {
     __shared__ float4 s_px[(kBlock * 3) / 4];
     const uint32_t base = blockIdx.x * kBlock;
     const uint32_t p = base + threadIdx.x;
     float x = 0.f, y = 0.f, z = 0.f;
     if (p < npix) {
-        const float4 c0 = cells[4 * p + 0], c1 = cells[4 * p + 1], c2 = cells[4 * p + 2], c3 = cells[4 * p + 3];
-        x = ((c0.x + c1.x) + c2.x) + c3.x;
-        y = ((c0.y + c1.y) + c2.y) + c3.y;
-        z = ((c0.z + c1.z) + c2.z) + c3.z;
+        const float4* c = cells + (size_t)p * 4u * nb;
+        float cx[4], cy[4], cz[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 a = c[g * nb];
+            for (uint32_t k = 1; k < nb; ++k) {
+                const float4 v = c[g * nb + k];
+                a.x += v.x; a.y += v.y; a.z += v.z;
+            }
+            cx[g] = a.x; cy[g] = a.y; cz[g] = a.z;
+        }
+        x = ((cx[0] + cx[1]) + cx[2]) + cx[3];
+        y = ((cy[0] + cy[1]) + cy[2]) + cy[3];
+        z = ((cz[0] + cz[1]) + cz[2]) + cz[3];
         if (normalise) { x *= scale; y *= scale; z *= scale; }
     }
     const bool full = base + kBlock <= npix;       // workgroup-uniform
@@ -607,13 +621,13 @@ extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int m
     return guard ? launch_variant<false, true, false, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 256>(P, blocks, lds, stream);
 }
 
-extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, hipStream_t stream)
+extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream)
 {
     const uint32_t blocks = (npix + spt::kBlock - 1) / spt::kBlock;
     if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)     // 256 pixels * 12 B = 3 KB per workgroup keeps every block base aligned
-        hipLaunchKernelGGL(spt::finalize<true>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise);
+        hipLaunchKernelGGL(spt::finalize<true>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise, nb);
     else
-        hipLaunchKernelGGL(spt::finalize<false>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise);
+        hipLaunchKernelGGL(spt::finalize<false>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise, nb);
     return hipGetLastError();
 }
 

@@ -17,9 +17,12 @@
 //     shading at ~18 % lane utilisation because a lane owns its path; here a batch is >= 93 % full
 //     (P = 128: three lists hold 128 entries, see tools/pool_sim.py) at the price of one LDS round trip of
 //     the 48-byte path state per bounce.  No cross-wave communication, no barriers after scene staging.
-//   * path state between the phases: {hit point, rbase} {direction, depth|branch|inst|refl} {weight, k1}
-//     as three float4 per slot; task state {cell sum, task id} {next sample | stack count}.  The <=3 pending
-//     transmitted children of the glass split (smallpt.cpp:252) live in a global-memory stack (rare).
+//   * LDS per slot (62 bytes): path state between the phases {hit point, rbase} {direction, depth|branch|inst|refl|
+//     stack count} {weight, k1} as three float4, the block sum of the task as three floats, one byte in the GEN list
+//     and one in the array shared by the DIFF list (growing up) and the REFR list (growing down).  {task id, next
+//     sample} of a slot (only needed when a new path starts) and the <= 3 pending transmitted children of the glass
+//     split (smallpt.cpp:252) live in global memory.  128 slots per wave = 31.6 KB per 256-thread workgroup: five
+//     workgroups (20 waves) per CU.
 //   * RNG (D7), summation order (D9), sin/cos (D17), depth cap (D18), zero-weight cut (D19) and every
 //     arithmetic expression are those of spt_kernel.hip / the oracle: results are bit-identical.
 #include "spt_device.h"
@@ -33,6 +36,7 @@ constexpr int kPoolBlock = 256;
 constexpr uint32_t kNoTask = 0xFFFFFFFFu;
 constexpr int kStackWords = 12;                                  // o.xyz d.xyz w.xyz (depth|branch<<16) k0 k1
 constexpr int kMaxUnroll = 24;                                   // spheres handled by the unrolled closest-hit code
+constexpr int kSlotBytes = 62;                                   // LDS per pool slot (layout in poolkernel)
 
 __device__ __forceinline__ uint32_t lane_id_p() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t rank_in(unsigned long long m)
@@ -40,12 +44,18 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// packed word of a waiting path: [11:0] depth, [14:12] branch bits (D7), [15] weight-may-be-non-finite flag,
-// [27:16] sphere index, [29:28] Refl_t
-__device__ __forceinline__ uint32_t pack_path(uint32_t depth, uint32_t branchf, uint32_t inst, uint32_t refl)
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
 {
-    return depth | (branchf << 12) | (inst << 16) | (refl << 28);
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// packed word of a slot: [11:0] depth, [14:12] branch bits (D7), [15] weight-may-be-non-finite flag,
+// [27:16] sphere index, [29:28] Refl_t, [31:30] pending transmitted children of the slot's current sample
+__device__ __forceinline__ uint32_t pack_path(uint32_t depth, uint32_t branchf, uint32_t inst, uint32_t refl, uint32_t sp)
+{
+    return depth | (branchf << 12) | (inst << 16) | (refl << 28) | (sp << 30);
 }
 
 enum { C_GEN = 0, C_DIFF = 1, C_REFR = 2 };
@@ -53,19 +63,21 @@ enum { C_GEN = 0, C_DIFF = 1, C_REFR = 2 };
 template <int P, int NG>
 __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
 {
-    static_assert(P % 64 == 0 || P == 96, "pool size");
+    static_assert(P % 32 == 0 && P <= 256, "pool size");
     extern __shared__ float4 lds[];
-    constexpr int kWaveF4 = (71 * P) / 16;                       // float4 per wave region (71 bytes per slot)
-    static_assert((71 * P) % 16 == 0, "wave region must be float4-aligned");
+    constexpr int kWaveF4 = (kSlotBytes * P) / 16;               // float4 per wave region
+    static_assert((kSlotBytes * P) % 16 == 0, "wave region must be float4-aligned");
     const uint32_t lane = lane_id_p();
     const uint32_t wave = threadIdx.x >> 6;
     float4* const A0 = lds + wave * kWaveF4;                     // {hx.xyz, rbase}
     float4* const A1 = A0 + P;                                   // {d.xyz, packed}
     float4* const A2 = A1 + P;                                   // {w.xyz, k1}
-    float4* const T0 = A2 + P;                                   // {cell sum xyz, task id}
-    uint32_t* const T1 = reinterpret_cast<uint32_t*>(T0 + P);    // next sample << 2 | pending stack entries
-    uint8_t* const LST = reinterpret_cast<uint8_t*>(T1 + P);     // 3 lists x P slot ids
-    float4* const s_geom = lds + (kPoolBlock / 64) * kWaveF4;    // n x {c.xyz, r*r}
+    float* const ACX = reinterpret_cast<float*>(A2 + P);         // block sum of the slot's task (D9), SoA
+    float* const ACY = ACX + P;
+    float* const ACZ = ACY + P;
+    uint8_t* const LG = reinterpret_cast<uint8_t*>(ACZ + P);     // GEN list
+    // LG[P .. 2P-1]: array shared by the DIFF list (from index 0 up) and the REFR list (from P-1 down)
+    float4* const s_geom = lds + (kPoolBlock / 64) * kWaveF4;    // 3 NG x {c.xyz, r*r}
     float4* const s_mat = s_geom + 3 * NG;                       // 3 x (3 NG) material rows
 
     for (uint32_t i = threadIdx.x; i < 3u * NG; i += kPoolBlock) {
@@ -76,14 +88,15 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         s_mat[3 * i + 2] = real ? K.mat[3 * i + 2] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // every slot starts on the GEN list as a finished, task-less slot
+    const uint32_t wave_gid = blockIdx.x * (kPoolBlock / 64) + wave;
+    uint2* const gtask = K.slot_state + (size_t)wave_gid * P;    // {task id, next sample} per slot
     for (uint32_t s = lane; s < (uint32_t)P; s += 64) {
-        T0[s] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoTask));
-        T1[s] = K.samps << 2;
-        LST[C_GEN * P + s] = (uint8_t)s;
+        gtask[s] = make_uint2(kNoTask, 0u);
+        A1[s].w = __uint_as_float(0u);                           // stack count 0
+        LG[s] = (uint8_t)s;
     }
     __syncthreads();
 
-    const uint32_t wave_gid = blockIdx.x * (kPoolBlock / 64) + wave;
     float* const gstack = K.stack + (size_t)wave_gid * (3 * kStackWords * P);
     auto stack_at = [&](uint32_t e, int f, uint32_t slot) -> float& { return gstack[(e * kStackWords + f) * P + slot]; };
 
@@ -121,27 +134,32 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         }
         if (c == C_GEN) { b = nG < 64u ? nG : 64u; nG -= b; lbase = nG; ++itG; lnG += b; }
         else if (c == C_DIFF) { b = nD < 64u ? nD : 64u; nD -= b; lbase = (uint32_t)P + nD; ++itD; lnD += b; }
-        else { b = nR < 64u ? nR : 64u; nR -= b; lbase = 2u * (uint32_t)P + nR; ++itR; lnR += b; }
+        else { b = nR < 64u ? nR : 64u; lbase = 2u * (uint32_t)P - nR; nR -= b; ++itR; lnR += b; }   // REFR entries: LDR[P-nR .. P-1]
         if (queue_empty) { ++itTail; lnTail += b; }
         if (b == 64u) ++itFull;
         if ((++it_total & 255u) == 0u && K.watchdog_ticks != 0ull &&
             __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
 
         const bool valid = lane < b;
-        const uint32_t slot = valid ? (uint32_t)LST[lbase + lane] : 0u;
+        const uint32_t slot = valid ? (uint32_t)LG[lbase + lane] : 0u;    // LDR follows LG: index P.. = LDR[0..]
 
         // per-lane path registers handed from the class code to the closest-hit query
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), w = mk(0, 0, 0);
-        uint32_t depth = 0, branchf = 0, rbase = 0, k1 = 0;
+        uint32_t depth = 0, branchf = 0, rbase = 0, k1 = 0, sp = 0;
         bool has_ray = false;
         bool retired = false;                                    // GEN only: no task left for this slot
 
         if (c == C_GEN) {
             // ================= GEN: continue the slot's task (smallpt.cpp:304-340, :252 pop) =================
-            const float4 t0 = T0[slot];
-            const uint32_t t1 = T1[slot];
-            uint32_t snext = t1 >> 2, sp = t1 & 3u;
-            uint32_t task = __float_as_uint(t0.w);
+            const uint2 ts = gtask[slot];
+            uint32_t task = ts.x, snext = ts.y;
+            sp = __float_as_uint(A1[slot].w) >> 30;
+            // task = ((pixel * 4 + cell) << nb_log2) | block (D9); a task-less slot has snext == send == 0
+            uint32_t send = 0;
+            if (task != kNoTask) {
+                const uint32_t sbeg = (task & ((1u << K.nb_log2) - 1u)) * K.sb;
+                send = sbeg + K.sb < K.samps ? sbeg + K.sb : K.samps;
+            }
             bool gen = false;
             bool need_task = false;
             if (valid) {
@@ -155,17 +173,16 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                     const uint32_t k0 = __float_as_uint(stack_at(sp, 10, slot));
                     k1 = __float_as_uint(stack_at(sp, 11, slot));
                     rbase = rng_base(k0, branchf & 7u, depth);
-                    T1[slot] = (snext << 2) | sp;
                     has_ray = true;
-                } else if (snext == K.samps) {
-                    need_task = true;                            // cell finished (or the slot never had a task)
+                } else if (snext == send) {
+                    need_task = true;                            // sample block finished (or the slot never had a task)
                 } else {
                     gen = true;
                 }
             }
             const unsigned long long need_mask = __ballot(need_task);
             if (need_mask != 0ull) {
-                if (need_task && task != kNoTask) K.cells[task] = make_float4(t0.x, t0.y, t0.z, 0.0f);
+                if (need_task && task != kNoTask) K.cells[task] = make_float4(ACX[slot], ACY[slot], ACZ[slot], 0.0f);
                 // wave-private chunks of task ids; only the refill touches the global queue word
                 const uint32_t cntn = (uint32_t)__popcll(need_mask);
                 const uint32_t rk = rank_in(need_mask);
@@ -191,8 +208,9 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 if (need_task) {
                     const uint32_t nt = rk < avail ? base_old + rk : base_new + (rk - avail);
                     if (nt < K.ntasks) {
-                        task = nt; snext = 0; gen = true;
-                        T0[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(task));
+                        task = nt; gen = true;
+                        snext = (task & ((1u << K.nb_log2) - 1u)) * K.sb;
+                        ACX[slot] = 0.f; ACY[slot] = 0.f; ACZ[slot] = 0.f;
                     } else {
                         retired = true;                          // the slot is pushed onto no list
                     }
@@ -200,7 +218,8 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             }
             if (gen) {
                 // ---- camera ray of sample `snext` of the cell (smallpt.cpp:325-340 / :745-760) ----
-                const uint32_t pix_local = task >> 2, cell = task & 3u;
+                const uint32_t cellid = task >> K.nb_log2;
+                const uint32_t pix_local = cellid >> 2, cell = cellid & 3u;
                 const uint32_t ry = pix_local / K.w;
                 const uint32_t px = pix_local - ry * K.w;
                 const uint32_t py = K.row_begin + ry;
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 o = cam_o + dd * K.cam_push;                                                    // :333
                 d = dd * inv;                                                                   // normalize(d)
                 w = mk(1, 1, 1); depth = 0; branchf = 0; rbase = k0;                             // :338-339
-                T1[slot] = (snext + 1u) << 2;
+                gtask[slot] = make_uint2(task, snext + 1u);
                 has_ray = true;
             }
         } else {
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             const uint32_t pk = valid ? __float_as_uint(a1.w) : 0u;       // idle lanes: sphere 0, never stored
             w = mk(a2.x, a2.y, a2.z);
             k1 = __float_as_uint(a2.w);
-            depth = pk & 0xFFFu; branchf = (pk >> 12) & 0xFu;
+            depth = pk & 0xFFFu; branchf = (pk >> 12) & 0xFu; sp = pk >> 30;
             const uint32_t inst = (pk >> 16) & 0xFFFu;
             const float4 gh = s_geom[inst];
             const f3 n = normalize<false>(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));       // scene.cpp:124
@@ -303,8 +322,6 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                     if (depth <= 2u) {                                                      // :248 split (D6)
                         const f3 tw = w * (f * Tr);
                         if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
-                            const uint32_t t1 = T1[slot];
-                            const uint32_t sp = t1 & 3u;
                             const uint32_t br = branchf & 7u;
                             const bool nonfin = !(__builtin_fabsf(tw.x) < __builtin_inff() && __builtin_fabsf(tw.y) < __builtin_inff() && __builtin_fabsf(tw.z) < __builtin_inff());
                             stack_at(sp, 0, slot) = xin.x; stack_at(sp, 1, slot) = xin.y; stack_at(sp, 2, slot) = xin.z;
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                             stack_at(sp, 9, slot) = __uint_as_float((depth + 1u) | ((br | (1u << depth) | ((branchf & 8u) | (nonfin ? 8u : 0u))) << 16));
                             stack_at(sp, 10, slot) = __uint_as_float(rbase - ((br << 29) | (depth << 2)) * kGolden);   // k0
                             stack_at(sp, 11, slot) = __uint_as_float(k1);
-                            T1[slot] = t1 + 1u;
+                            ++sp;
                         }
                         nf = f * Re;
                     } else {
@@ -346,8 +363,11 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         uint32_t next = C_GEN;                                   // slots without a continuing path go back to GEN
         const bool queued = valid && !retired;
         if (has_ray) {
-            uint32_t near_key = kInfKeyP;
-            uint32_t inst = 0;
+            // nk[i + 1] = min(nk[i], key1, key2) of sphere i: one v_min3_u32 per sphere; the index of the winner is
+            // recovered afterwards (hit lanes only) as the last i at which the running minimum changed = the lowest
+            // index among equal nearest distances (:61 strict <).
+            uint32_t nk[3 * NG + 1];
+            nk[0] = kInfKeyP;
 #define SPT_PSPH(i)                                                                         \
             if ((i) < 3 * NG) {                                                             \
                 const float4 g = s_geom[(i)];                                               \
@@ -357,26 +377,26 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 const float sd = sqrt_fix_int(det);                                         /* :134 */ \
                 const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;                  /* :135 */ \
                 const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;                  \
-                const uint32_t kmin = key1 < key2 ? key1 : key2;                            \
-                const uint32_t nn = kmin < near_key ? kmin : near_key;                      \
-                if (nn != near_key) inst = (i);                                             /* :61 strict <: lowest index wins ties */ \
-                near_key = nn;                                                              \
+                nk[(i) + 1] = umin3(nk[(i)], key1, key2);                                   \
             }
             SPT_PSPH(0) SPT_PSPH(1) SPT_PSPH(2) SPT_PSPH(3) SPT_PSPH(4) SPT_PSPH(5) SPT_PSPH(6) SPT_PSPH(7)
             SPT_PSPH(8) SPT_PSPH(9) SPT_PSPH(10) SPT_PSPH(11) SPT_PSPH(12) SPT_PSPH(13) SPT_PSPH(14) SPT_PSPH(15)
             SPT_PSPH(16) SPT_PSPH(17) SPT_PSPH(18) SPT_PSPH(19) SPT_PSPH(20) SPT_PSPH(21) SPT_PSPH(22) SPT_PSPH(23)
 #undef SPT_PSPH
+            const uint32_t near_key = nk[3 * NG];
             // ---- class-independent part of shadePaths (smallpt.cpp:168-198) ----
             if (near_key != kInfKeyP) {                                                     // else :168 miss (D13)
                 const float t = __uint_as_float(near_key + kEpsBias);
+                uint32_t inst = 0;
+#pragma unroll
+                for (int i = 1; i < 3 * NG; ++i)
+                    if (nk[i + 1] != nk[i]) inst = (uint32_t)i;
                 const float4 me = s_mat[3 * inst + 0];                                      // emission.xyz, refl | emissive << 2
                 const float4 mc = s_mat[3 * inst + 1];                                      // color.xyz, pmax
                 const uint32_t rb = __float_as_uint(me.w);
                 const uint32_t refl = rb & 3u;
                 if ((rb & 4u) != 0u || (branchf & 8u) != 0u) {                              // :179 (D4); + w*0 is skipped, exact for finite w
-                    float4 acc = T0[slot];
-                    acc.x = acc.x + w.x * me.x; acc.y = acc.y + w.y * me.y; acc.z = acc.z + w.z * me.z;
-                    T0[slot] = acc;
+                    ACX[slot] = ACX[slot] + w.x * me.x; ACY[slot] = ACY[slot] + w.y * me.y; ACZ[slot] = ACZ[slot] + w.z * me.z;
                 }
                 f3 f = mk(mc.x, mc.y, mc.z);                                                // :175
                 bool cont = true;
@@ -398,7 +418,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                     if (cont) {
                         const f3 hx = o + d * t;                                            // scene.cpp:137
                         A0[slot] = make_float4(hx.x, hx.y, hx.z, __uint_as_float(rbase));
-                        A1[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(pack_path(depth, branchf, inst, refl)));
+                        A1[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(pack_path(depth, branchf, inst, refl, sp)));
                         A2[slot] = make_float4(w.x, w.y, w.z, __uint_as_float(k1));
                         next = refl == 2u ? C_REFR : C_DIFF;
                     }
@@ -407,13 +427,16 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         }
         // ================= push every slot onto the list of its next class =================
         {
-            const unsigned long long mg = __ballot(queued && next == C_GEN);
+            const bool to_gen = queued && next == C_GEN;
+            const unsigned long long mg = __ballot(to_gen);
             const unsigned long long md = __ballot(queued && next == C_DIFF);
             const unsigned long long mr = __ballot(queued && next == C_REFR);
             uint32_t pos = nG + rank_in(mg);
             if (next == C_DIFF) pos = (uint32_t)P + nD + rank_in(md);
-            if (next == C_REFR) pos = 2u * (uint32_t)P + nR + rank_in(mr);
-            if (queued) LST[pos] = (uint8_t)slot;
+            if (next == C_REFR) pos = 2u * (uint32_t)P - 1u - nR - rank_in(mr);
+            if (queued) LG[pos] = (uint8_t)slot;
+            // a slot whose path ended keeps the count of its sample's pending transmitted children for the next GEN visit
+            if (to_gen) A1[slot].w = __uint_as_float(sp << 30);
             nG += (uint32_t)__popcll(mg);
             nD += (uint32_t)__popcll(md);
             nR += (uint32_t)__popcll(mr);
@@ -441,13 +464,15 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
 extern "C" size_t spt_pool_lds_bytes(uint32_t n, int pool)
 {
     const uint32_t ng = n == 0 ? 1u : (n + 2u) / 3u;
-    return (size_t)(spt::kPoolBlock / 64) * 71u * (size_t)pool + (size_t)ng * 3u * 64u;
+    return (size_t)(spt::kPoolBlock / 64) * (size_t)spt::kSlotBytes * (size_t)pool + (size_t)ng * 3u * 64u;
 }
 
 extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool)
 {
     return (size_t)blocks * (spt::kPoolBlock / 64) * 3u * spt::kStackWords * (size_t)pool;
 }
+
+extern "C" size_t spt_pool_state_bytes(uint32_t blocks, int pool) { return (size_t)blocks * (spt::kPoolBlock / 64) * (size_t)pool * sizeof(uint2); }
 
 extern "C" int spt_pool_max_spheres(void) { return spt::kMaxUnroll; }
 
@@ -480,6 +505,7 @@ extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, in
 {
     const size_t lds = spt_pool_lds_bytes(K->n, pool);
     if (pool == 128) return launch_pool_ng<128>(K, blocks, lds, stream);
+    if (pool == 160) return launch_pool_ng<160>(K, blocks, lds, stream);
 #ifdef SPT_POOL_SIZES
     if (pool == 96) return launch_pool_ng<96>(K, blocks, lds, stream);
     if (pool == 192) return launch_pool_ng<192>(K, blocks, lds, stream);

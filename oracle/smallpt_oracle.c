@@ -414,9 +414,22 @@ int orc_num_threads(void)
 #endif
 }
 
+/* D9 block layout of a jitter cell's `samps` samples: NB = 1, 2, 4 or 8 blocks (>= 16 samples each), SB = ceil(samps/NB)
+ * samples per block (the last block may be shorter, never empty). */
+void orc_sample_blocks(uint32_t samps, uint32_t* nb, uint32_t* sb)
+{
+    const uint32_t n = samps >= 128u ? 8u : (samps >= 64u ? 4u : (samps >= 32u ? 2u : 1u));
+    *nb = n;
+    *sb = (samps + n - 1u) / n;
+}
+
 /* cpuRender smallpt.cpp:269-361: per pixel/cell/sample in the order of
- * foreachSampleInRow (:294-314).  D9 accumulation order: every emission event is added straight
- * into its cell accumulator in (sample-major, DFS) order; the pixel is ((c0+c1)+c2)+c3. */
+ * foreachSampleInRow (:294-314).  D9 accumulation order: the reference adds weight*emission into the pixel in
+ * wavefront (depth-major) order across all samples of a row (:179, :349-356), which no path-owning worker can
+ * reproduce; the spec instead fixes: each jitter cell's samples are split into NB consecutive blocks
+ * (orc_sample_blocks); inside a block every emission event is added to the block accumulator in (sample-ascending,
+ * DFS pre-order) order; cell = ((B0 + B1) + B2) + ... in block order; pixel = ((c0 + c1) + c2) + c3.
+ * (Up to 31 samples per cell there is one block: the classic per-subpixel accumulator of smallpt.) */
 int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
                uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
                uint32_t samps, uint64_t seed, uint32_t flags, int threads,
@@ -428,6 +441,8 @@ int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
     if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return 1;
     uint64_t tot_b = 0, tot_k = 0;
     const uint32_t spp = 4 * samps;                                   /* :286 */
+    uint32_t nb, sb;
+    orc_sample_blocks(samps, &nb, &sb);
     /* The reference parallelises over rows (:317); here the unit is a chunk of 16 consecutive pixels so that a
      * band of a few rows still uses every core.  Pixels are independent, so the image does not depend on it. */
     const int64_t npix = (int64_t)row_count * w;
@@ -448,19 +463,24 @@ int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
             for (uint32_t sy = 0; sy < 2; ++sy)                       /* :299 */
                 for (uint32_t sx = 0; sx < 2; ++sx) {                 /* :301 */
                     const uint32_t g = sy * 2 + sx;                   /* :303 */
-                    f3 acc = mk(0, 0, 0);
-                    for (uint32_t s = 0; s < samps; ++s) {            /* :304 */
-                        const uint32_t index_in_pixel = g * samps + s; /* :306 */
-                        uint32_t k0, k1;
-                        orc_sample_keys(seed, pixel_idx, index_in_pixel, &k0, &k1);
-                        const float u1 = orc_rng_uniform(k0, k1, CTR_CAM(0));
-                        const float u2 = orc_rng_uniform(k0, k1, CTR_CAM(1));
-                        path_t p;
-                        camera_ray(cam, w, h, px, py, sx, sy, u1, u2, &p.o, &p.d);
-                        p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; /* :338-339 */
-                        trace_sample(&tc, p, k0, k1, &acc);
+                    f3 cellsum = mk(0, 0, 0);
+                    for (uint32_t blk = 0; blk < nb; ++blk) {         /* D9 blocks */
+                        const uint32_t s_end = (blk + 1) * sb < samps ? (blk + 1) * sb : samps;
+                        f3 acc = mk(0, 0, 0);
+                        for (uint32_t s = blk * sb; s < s_end; ++s) { /* :304 */
+                            const uint32_t index_in_pixel = g * samps + s; /* :306 */
+                            uint32_t k0, k1;
+                            orc_sample_keys(seed, pixel_idx, index_in_pixel, &k0, &k1);
+                            const float u1 = orc_rng_uniform(k0, k1, CTR_CAM(0));
+                            const float u2 = orc_rng_uniform(k0, k1, CTR_CAM(1));
+                            path_t p;
+                            camera_ray(cam, w, h, px, py, sx, sy, u1, u2, &p.o, &p.d);
+                            p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; /* :338-339 */
+                            trace_sample(&tc, p, k0, k1, &acc);
+                        }
+                        cellsum = blk == 0 ? acc : add(cellsum, acc);
                     }
-                    cell[g] = acc;
+                    cell[g] = cellsum;
                 }
             f3 c = add(add(add(cell[0], cell[1]), cell[2]), cell[3]);
             if (flags & ORC_FLAG_NORMALISE) c = scl(c, 1.0f / (float)spp); /* :360, operator/= */

@@ -85,6 +85,9 @@ void  orc_camera_ray(const orc_camera* cam, uint32_t w, uint32_t h, uint32_t px,
 /* smallpt.cpp:52 */
 int   orc_to_int(float x);
 
+/* D9: block layout of a jitter cell's samples in the accumulation order (nb = 1, 2, 4 or 8 blocks of sb samples) */
+void  orc_sample_blocks(uint32_t samps_per_cell, uint32_t* nb, uint32_t* sb);
+
 /* --- the render (cpuRender :269-361 restated) ---
  * Renders rows [row_begin, row_begin+row_count) of a w x h image into out (row_count*w*3 floats,
  * row 0 of the band first; row index 0 = bottom of the image, D14).
