@@ -15,6 +15,9 @@
  *     (smallpt.cpp:679-680,692-814), sole caller :922             device-resident, async)
  *   Intersector::traceRays + shadePaths per bounce              inside the megakernel; not exposed
  *     (smallpt.cpp:553-587,154-267)
+ *   accumBuffer += outImage under accumBufferMutex and the      spt_progressive_begin / _frame / _snapshot / _end
+ *     GL thread's copy of it (smallpt.cpp:881-883,924-940,       (accumulation buffer resident in HBM)
+ *     955-959)
  *   "Elapsed time" stderr line (smallpt.cpp:371-373,809-811)    spt_stats
  *   CHK_PRIME / rtpContextGetLastErrorString                    int status + spt_last_error()
  *     (smallpt.cpp:381-393)
@@ -129,6 +132,20 @@ int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uin
  * d_accum[i] = clear ? d_frame[i] : d_accum[i] + d_frame[i] for n floats (both 16-byte aligned, on this device);
  * enqueued on hip_stream (NULL = the context's stream).  Display weight = 1/(frames*spp) (smallpt.cpp:957). */
 int  spt_accumulate_device(spt_ctx* ctx, void* d_accum, const void* d_frame, uint64_t n, int clear, void* hip_stream);
+
+/* The render thread's frame loop (smallpt.cpp:895-942) with accumBuffer (:881-883) resident in HBM behind the boundary:
+ *   spt_progressive_begin    allocates the w*h*3 accumulation buffer and a frame buffer on the context's device;
+ *   spt_progressive_frame    = `outImage = renderer.render(camera, ..., sampleCountPerJitterCell, threadCount, seed)` (:922,
+ *                            un-normalised sum) followed by `accumBuffer (clear ? = : +=) outImage` (:927-937); blocking;
+ *   spt_progressive_snapshot = `image = accumBuffer` under the mutex (:955-959): copies the accumulation buffer to host
+ *                            memory in the layout drawWeightedRGBImage(const float*, w, h, weight[3]) takes (glutils.h:153,
+ *                            glutils.cpp:230-256: GL_RGB / GL_FLOAT rows, bottom row first); the caller supplies the weight
+ *                            1/(sampleCount*sampleCountPerPixel) of :957;
+ *   spt_progressive_end      frees the two buffers. */
+int  spt_progressive_begin(spt_ctx* ctx, uint32_t w, uint32_t h);
+int  spt_progressive_frame(spt_ctx* ctx, const spt_camera* cam, uint32_t samps_per_cell, uint64_t seed, int clear, spt_stats* stats);
+int  spt_progressive_snapshot(spt_ctx* ctx, float* out_rgb);
+int  spt_progressive_end(spt_ctx* ctx);
 
 /* Waits for the last launch of this context and fills stats (may be NULL). */
 int  spt_sync(spt_ctx* ctx, spt_stats* stats);

@@ -1,0 +1,72 @@
+/*
+ * smallpt_mi355x_multi.h -- multi-GPU front of the C-ABI (libsmallpt_mi355x_multi.so, links RCCL).
+ *
+ * The reference renders on exactly one device (rtpContextSetCudaDeviceNumbers(context, 1, &device) with device 0,
+ * smallpt.cpp:480-481) behind `Vector<float3> Renderer::render(...)` (smallpt.cpp:679-680,692-814; sole caller :922).
+ * This entry point keeps that call shape -- one call, one framebuffer -- and spreads it over the GPUs of one node:
+ *
+ *   * the image is split into contiguous row bands, band g = rows [g*h/G ...) (the reference's own unit of
+ *     parallelism is the row, smallpt.cpp:317,736); the RNG is keyed by the GLOBAL pixel index, so the assembled image
+ *     is bit-identical for every device count;
+ *   * one host thread + one spt_ctx + one HIP stream per device; every device renders its band with
+ *     spt_render_rows_device (include/smallpt_mi355x.h);
+ *   * the bands are assembled on the root device (device_ids[0]) by ONE exchange step: every other rank ncclSend()s
+ *     its rows, the root ncclRecv()s each band straight into its row-slice of the framebuffer, all receives fused in
+ *     one ncclGroupStart/End -- point-to-point over xGMI, 7 links into the root in parallel, no ring, no reduction.
+ *     The root's own band is rendered in place.  With one device no RCCL communicator is created at all
+ *     (unless SPT_MULTI_SELF_EXCHANGE is passed, which routes the root's band through a grouped self send/recv:
+ *     a rehearsal of the RCCL path for boxes with a single GPU).
+ *
+ * All functions return 0 on success; errors via spt_multi_last_error.  Not thread-safe; one call at a time.
+ */
+#ifndef SMALLPT_MI355X_MULTI_H
+#define SMALLPT_MI355X_MULTI_H
+
+#include "smallpt_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spt_multi spt_multi;
+
+#define SPT_MULTI_SELF_EXCHANGE 1u  /* create flag: with one device, still send the band through RCCL (self send/recv) */
+
+typedef struct spt_multi_stats {
+    uint64_t samples;          /* whole image */
+    uint64_t bounces;
+    uint64_t max_depth_kills;
+    float    render_ms;        /* slowest device: HIP-event time of its megakernel + store kernel          */
+    float    gather_ms;        /* root: HIP-event time of the RCCL exchange on its stream (0 with one device) */
+    float    total_ms;         /* host wall time of the call                                               */
+    uint32_t ndev;
+    uint32_t pad;
+} spt_multi_stats;
+
+/* device_ids[0] is the root (the framebuffer is assembled there).  ndev >= 1; ids must be distinct. */
+int  spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi** out);
+void spt_multi_destroy(spt_multi* m);
+const char* spt_multi_last_error(const spt_multi* m);   /* m may be NULL: last error of spt_multi_create */
+int  spt_multi_device_count(const spt_multi* m);
+
+/* Uploads the sphere table to every device (spt_set_scene). */
+int  spt_multi_set_scene(spt_multi* m, const spt_sphere* spheres, uint32_t n);
+
+/* Row band of rank `rank` of `world` for an image of height h: rows split as evenly as possible, the first h % world
+ * ranks get one more row; bands are in rank order = row order. */
+void spt_multi_row_band(uint32_t h, uint32_t world, uint32_t rank, uint32_t* row_begin, uint32_t* row_count);
+
+/* Renders the w x h image on all devices and assembles it on the root device.  out_rgb: host buffer of w*h*3 floats
+ * (may be NULL: the framebuffer then stays on the root device, see spt_multi_framebuffer).  Same conventions as
+ * spt_render (row 0 = bottom, SPT_FLAG_NORMALISE). */
+int  spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h,
+                      uint32_t samps_per_cell, uint64_t seed, uint32_t flags,
+                      float* out_rgb, spt_multi_stats* stats);
+
+/* Device pointer (root device) of the framebuffer assembled by the last spt_multi_render: w*h*3 floats. */
+void* spt_multi_framebuffer(spt_multi* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALLPT_MI355X_MULTI_H */

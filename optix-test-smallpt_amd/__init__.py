@@ -3,12 +3,13 @@ Celeborn2BeAlive/optix-test-smallpt.  The compute path is the gfx950 megakernel 
 include/smallpt_mi355x.h (csrc/); this package is the thin host-side mirror of the reference's
 scene structs and render entry points.  Import name: ``optix_test_smallpt_amd`` (see the shim at
 the repository root)."""
-from ._lib import INTERNAL_SYMBOLS, LIB_PATH, SYMBOLS, SptCamera, SptSphere, SptStats, load_library  # noqa: F401
-from .renderer import (FLAG_NORMALISE, ProgressiveRenderer, Renderer, SptError, pinhole_camera,  # noqa: F401
+from ._lib import (INTERNAL_SYMBOLS, LIB_PATH, MULTI_SYMBOLS, SYMBOLS, SptCamera, SptMultiStats, SptSphere, SptStats,  # noqa: F401
+                   load_library, load_multi_library)
+from .renderer import (FLAG_NORMALISE, MultiRenderer, ProgressiveRenderer, Renderer, SptError, pinhole_camera,  # noqa: F401
                        smallpt_camera, to_int, write_ppm)
 from .scene import (DIFF, REFR, SPEC, SPHERE_DTYPE, cornell9, make_spheres, random_spheres,  # noqa: F401
                     spheres_from_json, spheres_to_json)
 
-__all__ = ["Renderer", "ProgressiveRenderer", "SptError", "smallpt_camera", "pinhole_camera", "cornell9", "random_spheres", "make_spheres",
+__all__ = ["Renderer", "MultiRenderer", "ProgressiveRenderer", "SptError", "smallpt_camera", "pinhole_camera", "cornell9", "random_spheres", "make_spheres",
            "spheres_from_json", "spheres_to_json", "SPHERE_DTYPE", "DIFF", "SPEC", "REFR",
            "load_library", "to_int", "write_ppm", "FLAG_NORMALISE"]

@@ -43,6 +43,10 @@ SYMBOLS = {
     "spt_render_rows_device": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
     "spt_accumulate_device": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _P]),
+    "spt_progressive_begin": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "spt_progressive_frame": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint64, C.c_int, C.POINTER(SptStats)]),
+    "spt_progressive_snapshot": (C.c_int, [_P, _P]),
+    "spt_progressive_end": (C.c_int, [_P]),
     "spt_sync": (C.c_int, [_P, C.POINTER(SptStats)]),
     "spt_to_int": (C.c_int, [C.c_float]),
     "spt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
@@ -57,7 +61,45 @@ INTERNAL_SYMBOLS = {
     "spt_last_kernel": (C.c_int, [_P]),
 }
 
+class SptMultiStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("bounces", C.c_uint64), ("max_depth_kills", C.c_uint64),
+                ("render_ms", C.c_float), ("gather_ms", C.c_float), ("total_ms", C.c_float),
+                ("ndev", C.c_uint32), ("pad", C.c_uint32)]
+
+
+# every symbol include/smallpt_mi355x_multi.h declares (libsmallpt_mi355x_multi.so, links RCCL)
+MULTI_LIB_PATH = os.path.join(_HERE, "csrc", "libsmallpt_mi355x_multi.so")
+MULTI_SYMBOLS = {
+    "spt_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint32, C.POINTER(_P)]),
+    "spt_multi_destroy": (None, [_P]),
+    "spt_multi_last_error": (C.c_char_p, [_P]),
+    "spt_multi_device_count": (C.c_int, [_P]),
+    "spt_multi_set_scene": (C.c_int, [_P, _P, C.c_uint32]),
+    "spt_multi_row_band": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "spt_multi_render": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                   C.c_uint32, _P, C.POINTER(SptMultiStats)]),
+    "spt_multi_framebuffer": (_P, [_P]),
+}
+
 _lib = None
+_multi_lib = None
+
+
+def load_multi_library():
+    """Loads libsmallpt_mi355x_multi.so (multi-GPU front, RCCL) and binds every symbol; raises if it is missing."""
+    global _multi_lib
+    if _multi_lib is not None:
+        return _multi_lib
+    load_library()
+    if not os.path.exists(MULTI_LIB_PATH):
+        raise RuntimeError(f"{MULTI_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(MULTI_LIB_PATH)
+    for name, (res, args) in MULTI_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _multi_lib = lib
+    return lib
 
 
 def load_library():

@@ -48,6 +48,9 @@ struct spt_ctx {
     float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
     size_t stack_cap = 0;          // in floats
     bool last_was_pool = false;
+    float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
+    float* d_frame = nullptr;
+    uint32_t prog_w = 0, prog_h = 0;
     unsigned long long pool_stats[10] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
@@ -147,6 +150,8 @@ void spt_destroy(spt_ctx* c)
     if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_stack) (void)hipFree(c->d_stack);
+    if (c->d_accum) (void)hipFree(c->d_accum);
+    if (c->d_frame) (void)hipFree(c->d_frame);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -437,6 +442,53 @@ int spt_accumulate_device(spt_ctx* c, void* d_accum, const void* d_frame, uint64
     SPT_HIP(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     SPT_HIP(c, spt_k_accumulate(static_cast<float*>(d_accum), static_cast<const float*>(d_frame), (size_t)n, clear, st));
+    return 0;
+}
+
+// ---- render-thread frame loop with the accumulation buffer in HBM (smallpt.cpp:881-883,895-942,955-959) ----
+int spt_progressive_end(spt_ctx* c)
+{
+    if (!c) return 1;
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    if (c->d_accum) (void)hipFree(c->d_accum);
+    if (c->d_frame) (void)hipFree(c->d_frame);
+    c->d_accum = c->d_frame = nullptr;
+    c->prog_w = c->prog_h = 0;
+    return 0;
+}
+
+int spt_progressive_begin(spt_ctx* c, uint32_t w, uint32_t h)
+{
+    if (!c) return 1;
+    if (w == 0 || h == 0) return c->fail("spt_progressive_begin: empty image");
+    if (int rc = spt_progressive_end(c)) return rc;
+    const size_t bytes = (size_t)w * h * 3 * sizeof(float);
+    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_accum), bytes));
+    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_frame), bytes));
+    SPT_HIP(c, hipMemsetAsync(c->d_accum, 0, bytes, c->stream));       // accumBuffer.resize(w*h, make_float3(0,0,0)), :882
+    c->prog_w = w; c->prog_h = h;
+    return 0;
+}
+
+int spt_progressive_frame(spt_ctx* c, const spt_camera* cam, uint32_t samps, uint64_t seed, int clear, spt_stats* stats)
+{
+    if (!c) return 1;
+    if (!c->d_accum) return c->fail("spt_progressive_frame: call spt_progressive_begin first");
+    // :922 the frame is the UN-NORMALISED sum of Renderer::render; :927-937 accumBuffer (clear ? = : +=) outImage
+    if (int rc = spt_render_rows_device(c, cam, c->prog_w, c->prog_h, 0, c->prog_h, samps, seed, 0u, c->d_frame, nullptr)) return rc;
+    if (int rc = spt_accumulate_device(c, c->d_accum, c->d_frame, (uint64_t)c->prog_w * c->prog_h * 3, clear, nullptr)) return rc;
+    SPT_HIP(c, hipStreamSynchronize(c->stream));
+    return spt_sync(c, stats);
+}
+
+int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
+{
+    if (!c) return 1;
+    if (!c->d_accum || !out_rgb) return c->fail("spt_progressive_snapshot: no accumulation buffer or out_rgb is NULL");
+    SPT_HIP(c, hipSetDevice(c->device));
+    SPT_HIP(c, hipMemcpyAsync(out_rgb, c->d_accum, (size_t)c->prog_w * c->prog_h * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    SPT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -1,0 +1,315 @@
+// spt_multi.cpp -- include/smallpt_mi355x_multi.h: one host thread + context + stream per device, row bands, and
+// one RCCL exchange step (ncclSend per band, grouped ncclRecv into the root's framebuffer slices).
+#include "../../include/smallpt_mi355x_multi.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_multi_create_error;
+
+// One persistent worker per device: jobs are closures run with that device current (the reference spawns detached
+// threads per parallel section, ThreadUtils.h:29-48; here the threads live as long as the spt_multi).
+class Worker {
+public:
+    Worker() : thread_([this] { loop(); }) {}
+    ~Worker()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        thread_.join();
+    }
+    void submit(std::function<void()> job)        // by value: nothing dangles (cf. the capture bug at ThreadUtils.h:133)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            job_ = std::move(job);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return !busy_; });
+    }
+
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return quit_ || (busy_ && job_); });
+                if (quit_) return;
+                job = std::move(job_);
+                job_ = nullptr;
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                busy_ = false;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread thread_;
+};
+
+struct Rank {
+    int device = 0;
+    spt_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    ncclComm_t comm = nullptr;
+    float* d_band = nullptr;       // non-root ranks (and the root in self-exchange mode): this rank's rows
+    size_t band_cap = 0;           // in floats
+    std::string error;             // set by the rank's job
+    spt_stats stats{};
+    float gather_ms = 0.f;
+    Worker* worker = nullptr;
+};
+
+}  // namespace
+
+struct spt_multi {
+    std::vector<Rank> ranks;
+    uint32_t flags = 0;
+    bool use_rccl = false;
+    float* d_frame = nullptr;      // root device: w*h*3 floats
+    size_t frame_cap = 0;
+    std::string error;
+
+    int fail(const char* fmt, ...)
+    {
+        char buf[768];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return 1;
+    }
+    // runs fn(rank index) on every rank's worker thread and collects the first error
+    int on_all(const std::function<void(int)>& fn)
+    {
+        for (size_t i = 0; i < ranks.size(); ++i) {
+            ranks[i].error.clear();
+            ranks[i].worker->submit([&fn, i] { fn((int)i); });
+        }
+        for (auto& r : ranks) r.worker->wait();
+        for (size_t i = 0; i < ranks.size(); ++i)
+            if (!ranks[i].error.empty()) return fail("device %d: %s", ranks[i].device, ranks[i].error.c_str());
+        return 0;
+    }
+};
+
+#define RK_HIP(r, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) { (r).error = std::string(#call) + ": " + hipGetErrorString(e__); return; } \
+    } while (0)
+#define RK_NCCL(r, call)                                                                       \
+    do {                                                                                       \
+        ncclResult_t e__ = (call);                                                             \
+        if (e__ != ncclSuccess) { (r).error = std::string(#call) + ": " + ncclGetErrorString(e__); return; } \
+    } while (0)
+
+extern "C" {
+
+const char* spt_multi_last_error(const spt_multi* m) { return m ? m->error.c_str() : g_multi_create_error.c_str(); }
+int spt_multi_device_count(const spt_multi* m) { return m ? (int)m->ranks.size() : 0; }
+
+void spt_multi_row_band(uint32_t h, uint32_t world, uint32_t rank, uint32_t* row_begin, uint32_t* row_count)
+{
+    const uint32_t base = h / world, extra = h % world;
+    if (row_count) *row_count = base + (rank < extra ? 1u : 0u);
+    if (row_begin) *row_begin = rank * base + (rank < extra ? rank : extra);
+}
+
+void spt_multi_destroy(spt_multi* m)
+{
+    if (!m) return;
+    if (!m->ranks.empty() && m->ranks[0].worker) {
+        m->on_all([m](int i) {
+            Rank& r = m->ranks[(size_t)i];
+            (void)hipSetDevice(r.device);
+            if (r.stream) (void)hipStreamSynchronize(r.stream);
+            if (r.comm) (void)ncclCommDestroy(r.comm);
+            if (r.d_band) (void)hipFree(r.d_band);
+            if (i == 0 && m->d_frame) (void)hipFree(m->d_frame);
+            if (r.ev_a) (void)hipEventDestroy(r.ev_a);
+            if (r.ev_b) (void)hipEventDestroy(r.ev_b);
+            if (r.stream) (void)hipStreamDestroy(r.stream);
+            if (r.ctx) spt_destroy(r.ctx);
+        });
+    }
+    for (auto& r : m->ranks) delete r.worker;
+    delete m;
+}
+
+int spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi** out)
+{
+    if (!out) { g_multi_create_error = "spt_multi_create: out is NULL"; return 1; }
+    *out = nullptr;
+    if (!device_ids || ndev < 1) { g_multi_create_error = "spt_multi_create: need at least one device id"; return 1; }
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (device_ids[i] == device_ids[j]) { g_multi_create_error = "spt_multi_create: device ids must be distinct"; return 1; }
+    spt_multi* m = new spt_multi;
+    m->flags = flags;
+    m->use_rccl = ndev > 1 || (flags & SPT_MULTI_SELF_EXCHANGE);
+    m->ranks.resize((size_t)ndev);
+    for (int i = 0; i < ndev; ++i) {
+        m->ranks[(size_t)i].device = device_ids[i];
+        m->ranks[(size_t)i].worker = new Worker;
+    }
+    // contexts, streams, events -- each on its own thread with its device current
+    int rc = m->on_all([m](int i) {
+        Rank& r = m->ranks[(size_t)i];
+        if (spt_create(r.device, &r.ctx)) { r.error = spt_last_error(nullptr); return; }
+        RK_HIP(r, hipSetDevice(r.device));
+        RK_HIP(r, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        RK_HIP(r, hipEventCreate(&r.ev_a));
+        RK_HIP(r, hipEventCreate(&r.ev_b));
+    });
+    if (rc == 0 && m->use_rccl) {
+        // single-process communicator over all devices (rank i = device_ids[i]); ncclCommInitAll handles the grouping
+        std::vector<ncclComm_t> comms((size_t)ndev);
+        const ncclResult_t e = ncclCommInitAll(comms.data(), ndev, device_ids);
+        if (e != ncclSuccess) rc = m->fail("ncclCommInitAll over %d device(s): %s", ndev, ncclGetErrorString(e));
+        else
+            for (int i = 0; i < ndev; ++i) m->ranks[(size_t)i].comm = comms[(size_t)i];
+    }
+    if (rc) {
+        g_multi_create_error = "spt_multi_create: " + m->error;
+        spt_multi_destroy(m);
+        return 1;
+    }
+    *out = m;
+    return 0;
+}
+
+int spt_multi_set_scene(spt_multi* m, const spt_sphere* spheres, uint32_t n)
+{
+    if (!m) return 1;
+    return m->on_all([m, spheres, n](int i) {
+        Rank& r = m->ranks[(size_t)i];
+        if (spt_set_scene(r.ctx, spheres, n)) r.error = spt_last_error(r.ctx);
+    });
+}
+
+void* spt_multi_framebuffer(spt_multi* m) { return m ? m->d_frame : nullptr; }
+
+int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t samps, uint64_t seed,
+                     uint32_t flags, float* out_rgb, spt_multi_stats* stats)
+{
+    if (!m) return 1;
+    if (!cam) return m->fail("spt_multi_render: camera is NULL");
+    if (w == 0 || h == 0 || samps == 0) return m->fail("spt_multi_render: empty image or samps == 0");
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t world = (uint32_t)m->ranks.size();
+    const size_t nfl = (size_t)w * h * 3;
+    const bool self_exchange = world == 1 && m->use_rccl;
+
+    // 1. buffers + band render, every device on its own thread (bands with zero rows -- more devices than rows -- skip)
+    int rc = m->on_all([=](int i) {
+        Rank& r = m->ranks[(size_t)i];
+        uint32_t begin, count;
+        spt_multi_row_band(h, world, (uint32_t)i, &begin, &count);
+        RK_HIP(r, hipSetDevice(r.device));
+        if (i == 0 && nfl > m->frame_cap) {
+            if (m->d_frame) (void)hipFree(m->d_frame);
+            m->d_frame = nullptr; m->frame_cap = 0;
+            RK_HIP(r, hipMalloc(reinterpret_cast<void**>(&m->d_frame), nfl * sizeof(float)));
+            m->frame_cap = nfl;
+        }
+        const size_t band_fl = (size_t)count * w * 3;
+        float* dst;
+        if (i == 0 && !self_exchange) {
+            dst = m->d_frame + (size_t)begin * w * 3;          // the root's band is rendered in place
+        } else {
+            if (band_fl > r.band_cap) {
+                if (r.d_band) (void)hipFree(r.d_band);
+                r.d_band = nullptr; r.band_cap = 0;
+                RK_HIP(r, hipMalloc(reinterpret_cast<void**>(&r.d_band), band_fl * sizeof(float)));
+                r.band_cap = band_fl;
+            }
+            dst = r.d_band;
+        }
+        r.stats = spt_stats{};
+        if (count) {
+            if (spt_render_rows_device(r.ctx, cam, w, h, begin, count, samps, seed, flags, dst, r.stream)) { r.error = spt_last_error(r.ctx); return; }
+        }
+        // 2. the exchange step, enqueued behind the render on the same stream
+        r.gather_ms = 0.f;
+        if (m->use_rccl) {
+            RK_HIP(r, hipEventRecord(r.ev_a, r.stream));
+            if (i == 0) {
+                RK_NCCL(r, ncclGroupStart());
+                for (uint32_t p = self_exchange ? 0u : 1u; p < world; ++p) {
+                    uint32_t pb, pc;
+                    spt_multi_row_band(h, world, p, &pb, &pc);
+                    if (pc) RK_NCCL(r, ncclRecv(m->d_frame + (size_t)pb * w * 3, (size_t)pc * w * 3, ncclFloat, (int)p, r.comm, r.stream));
+                }
+                if (self_exchange && count) RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
+                RK_NCCL(r, ncclGroupEnd());
+            } else if (count) {
+                RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
+            }
+            RK_HIP(r, hipEventRecord(r.ev_b, r.stream));
+        }
+        RK_HIP(r, hipStreamSynchronize(r.stream));
+        if (count && spt_sync(r.ctx, &r.stats)) { r.error = spt_last_error(r.ctx); return; }
+        if (m->use_rccl) RK_HIP(r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
+    });
+    if (rc) return rc;
+
+    // 3. framebuffer to the host if asked for
+    if (out_rgb) {
+        rc = 0;
+        Rank& r0 = m->ranks[0];
+        r0.error.clear();
+        r0.worker->submit([&] {
+            RK_HIP(r0, hipSetDevice(r0.device));
+            RK_HIP(r0, hipMemcpy(out_rgb, m->d_frame, nfl * sizeof(float), hipMemcpyDeviceToHost));
+        });
+        r0.worker->wait();
+        if (!r0.error.empty()) return m->fail("device %d: %s", r0.device, r0.error.c_str());
+    }
+    if (stats) {
+        *stats = spt_multi_stats{};
+        stats->ndev = world;
+        for (const Rank& r : m->ranks) {
+            stats->samples += r.stats.samples;
+            stats->bounces += r.stats.bounces;
+            stats->max_depth_kills += r.stats.max_depth_kills;
+            const float ms = r.stats.kernel_ms + r.stats.finalize_ms;
+            if (ms > stats->render_ms) stats->render_ms = ms;
+        }
+        stats->gather_ms = m->ranks[0].gather_ms;
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "scene.hpp"
+#include "../../include/smallpt_mi355x_multi.h"
 
 namespace spt_host {
 
@@ -45,6 +46,15 @@ public:
         return out;
     }
 
+    // accumBuffer of the viewer loop in HBM (spt_progressive_*, smallpt.cpp:881-883,922-937,955-959)
+    void progressiveBegin(size_t w, size_t h) { check(spt_progressive_begin(ctx_, (uint32_t)w, (uint32_t)h)); }
+    void progressiveFrame(const spt_camera& camera, size_t sampleCountPerJitterCell, size_t seed, bool clear)
+    {
+        check(spt_progressive_frame(ctx_, &camera, (uint32_t)sampleCountPerJitterCell, (uint64_t)seed, clear ? 1 : 0, &stats_));
+    }
+    void progressiveSnapshot(std::vector<float3>& image) { check(spt_progressive_snapshot(ctx_, reinterpret_cast<float*>(image.data()))); }
+    void progressiveEnd() { check(spt_progressive_end(ctx_)); }
+
     const spt_stats& stats() const { return stats_; }
     spt_ctx* handle() { return ctx_; }
 
@@ -55,6 +65,44 @@ private:
     }
     spt_ctx* ctx_ = nullptr;
     spt_stats stats_{};
+};
+
+// The same call spread over the GPUs of one node (include/smallpt_mi355x_multi.h): one host thread + context per
+// device, contiguous row bands, one RCCL exchange into the root device's framebuffer.  The reference is single-device
+// (smallpt.cpp:480-481); the image is bit-identical for every device count.
+class MultiRenderer {
+public:
+    explicit MultiRenderer(const std::vector<int>& devices, bool selfExchange = false)
+    {
+        if (spt_multi_create(devices.data(), (int)devices.size(), selfExchange ? SPT_MULTI_SELF_EXCHANGE : 0u, &m_))
+            throw std::runtime_error(spt_multi_last_error(nullptr));
+    }
+    ~MultiRenderer() { spt_multi_destroy(m_); }
+    MultiRenderer(const MultiRenderer&) = delete;
+    MultiRenderer& operator=(const MultiRenderer&) = delete;
+
+    void setScene(const std::vector<Sphere>& spheres)
+    {
+        const std::vector<spt_sphere> abi = to_abi(spheres);
+        check(spt_multi_set_scene(m_, abi.data(), (uint32_t)abi.size()));
+    }
+    std::vector<float3> render(const spt_camera& camera, size_t imageWidth, size_t imageHeight,
+                               size_t sampleCountPerJitterCell, size_t seed, bool normalise = false)
+    {
+        std::vector<float3> out(imageWidth * imageHeight);
+        check(spt_multi_render(m_, &camera, (uint32_t)imageWidth, (uint32_t)imageHeight, (uint32_t)sampleCountPerJitterCell,
+                               (uint64_t)seed, normalise ? SPT_FLAG_NORMALISE : 0u, reinterpret_cast<float*>(out.data()), &stats_));
+        return out;
+    }
+    const spt_multi_stats& stats() const { return stats_; }
+
+private:
+    void check(int rc)
+    {
+        if (rc) throw std::runtime_error(spt_multi_last_error(m_));
+    }
+    spt_multi* m_ = nullptr;
+    spt_multi_stats stats_{};
 };
 
 }  // namespace spt_host

@@ -223,6 +223,18 @@ Scene load_scene_json(const std::string& text)
     return sc;
 }
 
+// render request of the viewer's queue, smallpt.cpp:909-916: {"action": "update_camera", "org": [x, y, z]}
+bool parse_update_camera_request(const std::string& text, float3* org)
+{
+    Parser p(text);
+    JPtr root = p.parse();
+    if (root->kind != JValue::Object) throw std::runtime_error("render request: expected a JSON object");
+    auto a = root->obj.find("action");
+    if (a == root->obj.end() || a->second->kind != JValue::String || a->second->str != "update_camera") return false;
+    *org = vec3(member(*root, "org"), "org");
+    return true;
+}
+
 Scene load_scene_file(const std::string& path)
 {
     std::ifstream f(path, std::ios::binary);

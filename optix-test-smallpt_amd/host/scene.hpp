@@ -63,4 +63,8 @@ Scene load_scene_json(const std::string& text);
 Scene load_scene_file(const std::string& path);
 std::string scene_to_json(const Scene& scene);
 
+// One message of the viewer's request queue (smallpt.cpp:909-916,981-984), parsed with the same JSON reader:
+// true + org for {"action":"update_camera","org":[x,y,z]}, false for other actions; throws on malformed text.
+bool parse_update_camera_request(const std::string& text, float3* org);
+
 }  // namespace spt_host

@@ -5,14 +5,22 @@
 //
 //   smallpt_mi355x [spp] [--scene file.json] [--size WxH] [--seed N] [--out image.ppm] [--device D]
 //                  [--dump-scene out.json] [--parse-only]
+//                  [--devices 0,1,...] [--self-exchange]      row bands over several GPUs + RCCL exchange (MultiRenderer)
+//   smallpt_mi355x [spp] --viewer [--frames N] [--request JSON] [--frames-after M] [--threaded] [--org x,y,z]
+//                  [--dump-raw accum.bin]                      main()'s progressive loop (smallpt.cpp:840-1005) without the
+//                                                              window: N frames, then the request(s), then M frames; writes the
+//                                                              normalised image like the exit path (:995-1004)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "renderer.hpp"
+#include "viewer.hpp"
 
 using namespace spt_host;
 
@@ -21,7 +29,13 @@ int main(int argc, char* argv[])
     int spp = 4, w = 256, h = 256, device = 0;       // smallpt.cpp:274-276 defaults
     unsigned long long seed = 0;
     std::string scene_path, out_path = "image.ppm", dump_path;
-    bool parse_only = false;
+    bool parse_only = false, viewer = false, threaded = false, self_exchange = false;
+    int frames = 1, frames_after = 0;
+    std::vector<int> devices;
+    std::vector<std::string> requests;
+    std::string dump_raw;
+    float org[3] = {0, -1, 0};
+    bool have_org = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value after %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -32,6 +46,23 @@ int main(int argc, char* argv[])
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--dump-scene") dump_path = next();
         else if (a == "--parse-only") parse_only = true;
+        else if (a == "--parse-request") {   // host-only: one message of the viewer's request queue through the JSON reader
+            try {
+                float3 o3;
+                if (parse_update_camera_request(next(), &o3)) std::printf("update_camera %.9g %.9g %.9g\n", o3.x, o3.y, o3.z);
+                else std::printf("ignored\n");
+                return 0;
+            } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+        }
+        else if (a == "--viewer") viewer = true;
+        else if (a == "--threaded") threaded = true;
+        else if (a == "--self-exchange") self_exchange = true;
+        else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--frames-after") frames_after = std::atoi(next());
+        else if (a == "--request") requests.push_back(next());
+        else if (a == "--dump-raw") dump_raw = next();
+        else if (a == "--org") { if (std::sscanf(next(), "%f,%f,%f", &org[0], &org[1], &org[2]) != 3) { std::fprintf(stderr, "--org x,y,z\n"); return 2; } have_org = true; }
+        else if (a == "--devices") { const char* p = next(); while (*p) { devices.push_back((int)std::strtol(p, const_cast<char**>(&p), 10)); if (*p == ',') ++p; } }
         else if (a[0] != '-') spp = std::atoi(a.c_str());
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -47,9 +78,60 @@ int main(int argc, char* argv[])
             return 0;
         }
         const int samps = spp / 4 > 0 ? spp / 4 : 1;                               // :276
+        if (viewer) {
+            // main() of the reference (smallpt.cpp:840-1005) without GLFW/GL: render thread + request queue + accumulation
+            Renderer renderer(device);
+            renderer.setScene(scene.spheres);
+            Camera camera = defaultViewerCamera();
+            if (have_org) camera.org = make_float3(org[0], org[1], org[2]);
+            ProgressiveRenderer prog(renderer, (size_t)w, (size_t)h, (size_t)samps, camera);
+            auto run_frames = [&](int n) {
+                if (n <= 0) return;
+                if (threaded) {
+                    const size_t target = prog.framesRendered() + (size_t)n;
+                    prog.start();
+                    while (prog.framesRendered() < target) std::this_thread::yield();
+                    prog.stop();
+                } else {
+                    for (int k = 0; k < n; ++k) prog.stepOnce();
+                }
+            };
+            run_frames(frames);
+            for (const std::string& r : requests) prog.postRequest(r);
+            run_frames(frames_after);
+            std::vector<float3> image;
+            float weight3[3];
+            prog.snapshot(image, weight3);       // what the GL loop hands to drawWeightedRGBImage(image, w, h, weight3), :955-962
+            std::fprintf(stderr, "viewer: frames rendered %zu, sampleCount %zu, weight %.9g\n", prog.framesRendered(), prog.sampleCount(), weight3[0]);
+            if (!dump_raw.empty()) {
+                std::ofstream f(dump_raw, std::ios::binary);
+                f.write(reinterpret_cast<const char*>(image.data()), (std::streamsize)(image.size() * sizeof(float3)));
+            }
+            const std::vector<float3> fin = prog.finalImage();                          // :995-1001
+            if (spt_write_ppm(out_path.c_str(), reinterpret_cast<const float*>(fin.data()), (uint32_t)w, (uint32_t)h)) {   // :1003-1004
+                std::fprintf(stderr, "cannot write %s\n", out_path.c_str());
+                return 1;
+            }
+            return 0;
+        }
         const spt_camera cam = make_camera(scene.camera, (uint32_t)w, (uint32_t)h);  // :277-279
         std::fprintf(stderr, "Starting rendering\n");                               // :272
         const auto start = std::chrono::high_resolution_clock::now();
+        if (!devices.empty()) {
+            MultiRenderer multi(devices, self_exchange);
+            multi.setScene(scene.spheres);
+            std::vector<float3> c = multi.render(cam, (size_t)w, (size_t)h, (size_t)samps, (size_t)seed, /*normalise=*/true);
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
+            const spt_multi_stats& st = multi.stats();
+            std::fprintf(stderr, "Rendering (%d spp) 100.00%%\nElapsed time: %lld ms\n", samps * 4, (long long)ms);
+            std::fprintf(stderr, "%u device(s): render %.3f ms, RCCL exchange %.3f ms, %.1f Msamples/s, %.3f bounces/sample\n", st.ndev,
+                         st.render_ms, st.gather_ms, st.samples / (st.total_ms * 1e3), (double)st.bounces / (double)st.samples);
+            if (spt_write_ppm(out_path.c_str(), reinterpret_cast<const float*>(c.data()), (uint32_t)w, (uint32_t)h)) {
+                std::fprintf(stderr, "cannot write %s\n", out_path.c_str());
+                return 1;
+            }
+            return 0;
+        }
         Renderer renderer(device);
         renderer.setScene(scene.spheres);
         std::vector<float3> c = renderer.render(cam, (size_t)w, (size_t)h, (size_t)samps, (size_t)seed, /*normalise=*/true);

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import SptCamera, SptStats, load_library
+from ._lib import SptCamera, SptMultiStats, SptStats, load_library, load_multi_library
 from .scene import SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
@@ -148,6 +148,64 @@ class Renderer:
         st = SptStats()
         self._check(self._lib.spt_sync(self._h, C.byref(st)))
         return _stats_dict(st)
+
+
+class MultiRenderer:
+    """spt_multi_* (include/smallpt_mi355x_multi.h): ONE process, one host thread + context per device, row bands,
+    RCCL exchange into the root device's framebuffer.  `self_exchange` routes a single device's band through RCCL too
+    (rehearsal of the exchange step on a one-GPU box)."""
+
+    SELF_EXCHANGE = 1
+
+    def __init__(self, device_ids=(0,), self_exchange=False):
+        self._lib = load_multi_library()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        if self._lib.spt_multi_create(ids, len(device_ids), self.SELF_EXCHANGE if self_exchange else 0, C.byref(h)):
+            raise SptError(self._lib.spt_multi_last_error(None).decode())
+        self._h = h
+        self.device_ids = tuple(int(d) for d in device_ids)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.spt_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise SptError(self._lib.spt_multi_last_error(self._h).decode())
+
+    def set_scene(self, spheres):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        self._check(self._lib.spt_multi_set_scene(self._h, spheres.ctypes.data_as(C.c_void_p), len(spheres)))
+
+    def render(self, w, h, samps_per_cell, seed=0, normalise=False, camera=None, to_host=True):
+        """Returns ((h, w, 3) float32 image or None, stats dict); with to_host=False the framebuffer stays on the root
+        device (``framebuffer_ptr()``)."""
+        cam = camera if camera is not None else smallpt_camera(w, h)
+        out = np.empty((h, w, 3), dtype=np.float32) if to_host else None
+        st = SptMultiStats()
+        self._check(self._lib.spt_multi_render(self._h, C.byref(cam), w, h, samps_per_cell, seed,
+                                               FLAG_NORMALISE if normalise else 0,
+                                               out.ctypes.data_as(C.c_void_p) if to_host else None, C.byref(st)))
+        return out, {"samples": int(st.samples), "bounces": int(st.bounces), "max_depth_kills": int(st.max_depth_kills),
+                     "render_ms": float(st.render_ms), "gather_ms": float(st.gather_ms), "total_ms": float(st.total_ms),
+                     "ndev": int(st.ndev)}
+
+    def framebuffer_ptr(self):
+        return self._lib.spt_multi_framebuffer(self._h)
 
 
 class ProgressiveRenderer:

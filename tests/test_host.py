@@ -141,3 +141,19 @@ def test_cpp_json_loader_rejects_malformed(tmp_path):
         p.write_text(bad)
         r = subprocess.run([CLI, "--scene", str(p), "--parse-only"], capture_output=True)
         assert r.returncode == 1 and b"scene JSON" in r.stderr
+
+
+def test_viewer_request_messages_through_the_json_reader():
+    """The render-request format of the viewer queue (smallpt.cpp:909-916,981-984), parsed by the C++ host's own reader."""
+    import subprocess
+    cli = os.path.join(ROOT, "optix-test-smallpt_amd", "host", "smallpt_mi355x")
+    run = lambda msg: subprocess.run([cli, "--parse-request", msg], capture_output=True, text=True)
+    r = run('{"action": "update_camera", "org": [0.5, -0.99, 2]}')
+    assert r.returncode == 0 and r.stdout.split()[0] == "update_camera"
+    assert [np.float32(v) for v in r.stdout.split()[1:]] == [np.float32(0.5), np.float32(-0.99), np.float32(2)]
+    r = run('{"org": [1, 2, 3], "action": "update_camera"}')
+    assert r.returncode == 0 and r.stdout.split() == ["update_camera", "1", "2", "3"]
+    assert run('{"action": "something_else"}').stdout.strip() == "ignored"
+    assert run('{"action": "update_camera"}').returncode == 1            # org missing
+    assert run('{"action": "update_camera", "org": [1, 2]}').returncode == 1
+    assert run('{"action": "update_camera", "org": [1, 2, 3]').returncode == 1      # malformed JSON

@@ -1,0 +1,75 @@
+"""Multi-GPU front (include/smallpt_mi355x_multi.h, libsmallpt_mi355x_multi.so): the single-process, thread-per-device
+host with the RCCL exchange.  CPU part: the library loads (it links librccl), exports what its header declares, its row
+partition equals the Python one.  GPU part (one-GPU box): ndev = 1 gives the image of spt_render, also when the band is
+routed through RCCL (grouped self send/recv), which is the exchange step of the 8-GPU configuration at world size 1."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "smallpt_mi355x_multi.h")
+
+
+def test_multi_library_exports_header(pkg):
+    lib = pkg.load_multi_library()
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(spt_multi_[a-z_0-9]+)\s*\(", text)))
+    assert len(declared) >= 8 and sorted(pkg.MULTI_SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name)
+    assert C.sizeof(pkg.SptMultiStats) == 48
+
+
+def test_row_bands_equal_python_partition(pkg):
+    from optix_test_smallpt_amd.distributed import row_band
+    lib = pkg.load_multi_library()
+    b, c = C.c_uint32(), C.c_uint32()
+    for h in (1, 2, 7, 8, 9, 768, 4096, 4099):
+        for world in (1, 2, 3, 4, 8):
+            total = 0
+            for rank in range(world):
+                lib.spt_multi_row_band(h, world, rank, C.byref(b), C.byref(c))
+                assert (b.value, c.value) == row_band(h, world, rank)
+                assert b.value == total
+                total += c.value
+            assert total == h
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_multi_create_fails_without_gpu(pkg):
+    with pytest.raises(pkg.SptError, match="no CPU fallback"):
+        pkg.MultiRenderer((0,))
+    lib = pkg.load_multi_library()
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.spt_multi_create(ids, 2, 0, C.byref(h)) != 0 and b"distinct" in lib.spt_multi_last_error(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("self_exchange", [False, True])
+def test_single_device_multi_equals_spt_render(pkg, renderer, self_exchange):
+    w, h, samps, seed = 96, 70, 3, 11
+    sc = pkg.cornell9()
+    renderer.set_scene(sc)
+    ref, rst = renderer.render(w, h, samps, seed=seed, normalise=True)
+    with pkg.MultiRenderer((0,), self_exchange=self_exchange) as m:
+        m.set_scene(sc)
+        img, st = m.render(w, h, samps, seed=seed, normalise=True)
+        assert np.array_equal(img, ref)
+        assert st["bounces"] == rst["bounces"] and st["samples"] == rst["samples"] and st["ndev"] == 1
+        if self_exchange:
+            assert st["gather_ms"] > 0          # the band really went through ncclSend / ncclRecv
+        # second call reuses the buffers; device-resident variant
+        img2, _ = m.render(w, h, samps, seed=seed + 1, normalise=True, to_host=False)
+        assert img2 is None and m.framebuffer_ptr()
+
+
+@pytest.mark.gpu
+def test_multi_rejects_missing_device(pkg):
+    n = torch.cuda.device_count()
+    with pytest.raises(pkg.SptError, match="out of range"):
+        pkg.MultiRenderer((0, n + 3))
