@@ -99,7 +99,7 @@ def main():
     import torch
     import torch.distributed as dist
     import optix_test_smallpt_amd as pkg
-    from optix_test_smallpt_amd.distributed import gather_rows, row_band
+    from optix_test_smallpt_amd.distributed import FrameAssembler, row_band
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,16 +128,19 @@ def main():
     r.set_scene(pkg.cornell9())
     if args.variant:
         r.set_tuning(0, args.variant)
-    band = torch.empty((count, W, 3), dtype=torch.float32, device=dev)
+    # destination memory of the exchange: rank 0 owns the whole framebuffer and renders its band in place, the other
+    # ranks render into their band tensor; the bands are received straight into the framebuffer's row slices
+    fa = FrameAssembler(W, h, device=dev if backend == "nccl" else "cpu")
+    band = fa.band if backend == "nccl" else torch.empty((count, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         r.render_rows_device(band, W, h, begin, count, samps, seed=0, normalise=True, stream=stream)
         if world > 1 and backend != "nccl":
             st = r.sync()
-            full = gather_rows(band.cpu(), W, h)
-            return full, st
-        full = gather_rows(band, W, h) if world > 1 else band
+            fa.band.copy_(band)          # rehearsal transport: through host memory
+            return fa.gather(), st
+        full = fa.gather() if world > 1 else band
         st = r.sync()
         return full, st
 
@@ -150,7 +153,7 @@ def main():
     if world > 1:
         # communicator set-up (RCCL channels over xGMI are created lazily on the first collective) stays outside
         # the timed region even with --warmup 0
-        gather_rows(band if backend == "nccl" else band.cpu(), W, h)
+        fa.gather()
     for _ in range(args.warmup):
         step()
     fence()
@@ -196,7 +199,7 @@ def main():
                        "spheres": N_SPHERES, "width": W, "height": h, "spp": 4 * samps, "rows_per_gpu": count},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "spt::megakernel", "kernel_ms": round(k_s * 1e3, 3),
+                         "kernel": "spt::poolkernel" if r.last_kernel() == "pool" else "spt::megakernel", "kernel_ms": round(k_s * 1e3, 3),
                          "flops_per_sample": round(fl, 1), "bounces_per_sample": round(bbar, 4),
                          "note": "FP32 VALU-bound (no MFMA-shaped work, HBM traffic ~12 B/pixel/launch); algorithmic "
                                  "flops per SURVEY.md 8(d); arithmetic is non-contracted IEEE mul/add (1 flop/instr) "

@@ -3,9 +3,11 @@ with an RCCL gather over xGMI").  One process per GPU under torch.distributed; t
 partition is the image row, the reference's own unit of parallelism (smallpt.cpp:317,736).
 
 The RNG is keyed by the GLOBAL pixel index, so the assembled image is bit-identical for any world
-size.  The only exchange step is one gather of row_count*w*3 floats per rank to rank 0 (no
-reduction); with the nccl backend that is RCCL send/recv over xGMI, 7 point-to-point links into
-the root in parallel.
+size.  The only exchange step moves row_count*w*3 floats per rank to rank 0 (no reduction): every other
+rank sends its band, the root receives each band STRAIGHT INTO ITS ROW-SLICE of one framebuffer
+(batched point-to-point ops = grouped ncclSend/ncclRecv with the nccl backend: 7 xGMI links into the
+root in parallel, no ring, no staging copies, no concatenation).  The root renders its own band in
+place.  The single-process C++ counterpart is csrc/spt_multi.cpp (include/smallpt_mi355x_multi.h).
 """
 import torch
 import torch.distributed as dist
@@ -20,29 +22,52 @@ def row_band(h, world_size, rank):
     return begin, count
 
 
+class FrameAssembler:
+    """Owns the destination memory of the exchange: on `dst` the whole (h, w, 3) framebuffer, elsewhere this rank's
+    band.  ``band`` is the tensor a rank renders into (on dst: a view of its rows inside the framebuffer);
+    ``gather()`` runs the exchange and returns the framebuffer on dst, None elsewhere."""
+
+    def __init__(self, w, h, device="cpu", group=None, dst=0, dtype=torch.float32):
+        self.w, self.h, self.group, self.dst = w, h, group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.begin, self.count = row_band(h, self.world, self.rank)
+        if self.rank == dst:
+            self.frame = torch.empty((h, w, 3), dtype=dtype, device=device)
+            self.band = self.frame[self.begin:self.begin + self.count]
+        else:
+            self.frame = None
+            self.band = torch.empty((self.count, w, 3), dtype=dtype, device=device)
+
+    def gather(self):
+        if self.world == 1:
+            return self.frame
+        ops = []
+        if self.rank == self.dst:
+            for r in range(self.world):
+                b, c = row_band(self.h, self.world, r)
+                if r != self.dst and c:
+                    ops.append(dist.P2POp(dist.irecv, self.frame[b:b + c], r, self.group))
+        elif self.count:
+            ops.append(dist.P2POp(dist.isend, self.band, self.dst, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return self.frame
+
+
 def gather_rows(band, w, h, group=None, dst=0):
-    """Assembles the (h, w, 3) framebuffer on rank `dst` from every rank's (count, w, 3) band.
-    Returns the full image tensor on dst, None elsewhere.  Uneven bands are padded to the largest
-    band so that one collective moves everything."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    begin, count = row_band(h, world, rank)
-    assert band.shape == (count, w, 3), (band.shape, count, w)
-    if world == 1:
+    """Assembles the (h, w, 3) framebuffer on rank `dst` from every rank's (count, w, 3) band (a convenience over
+    FrameAssembler for callers that already hold their band: costs one device copy of the root's own rows)."""
+    fa = FrameAssembler(w, h, device=band.device, group=group, dst=dst, dtype=band.dtype)
+    assert band.shape == (fa.count, w, 3), (band.shape, fa.count, w)
+    if fa.world == 1:
         return band
-    max_count = row_band(h, world, 0)[1]
-    if count != max_count:
-        padded = band.new_zeros((max_count, w, 3))
-        padded[:count] = band
+    if fa.rank == dst:
+        fa.band.copy_(band)
     else:
-        padded = band.contiguous()
-    if rank == dst:
-        parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.gather(padded, parts, dst=dst, group=group)
-        rows = [parts[r][: row_band(h, world, r)[1]] for r in range(world)]
-        return torch.cat(rows, dim=0)
-    dist.gather(padded, None, dst=dst, group=group)
-    return None
+        fa.band = band.contiguous()
+    return fa.gather()
 
 
 def render_distributed(render_band, w, h, group=None, dst=0):

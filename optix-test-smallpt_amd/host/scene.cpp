@@ -99,6 +99,8 @@ public:
 private:
     const std::string& s_;
     size_t i_ = 0;
+    int depth_ = 0;                          // nesting of arrays/objects; bounded so that hostile input cannot overflow the stack
+    static constexpr int kMaxDepth = 64;
 
     [[noreturn]] void fail(const char* what) const
     {
@@ -116,9 +118,10 @@ private:
         if (i_ >= s_.size()) fail("unexpected end");
         auto v = std::make_shared<JValue>();
         const char c = s_[i_];
+        if ((c == '{' || c == '[') && ++depth_ > kMaxDepth) fail("nesting too deep");
         if (c == '{') {
             ++i_; v->kind = JValue::Object;
-            if (eat('}')) return v;
+            if (eat('}')) { --depth_; return v; }
             do {
                 ws();
                 if (i_ >= s_.size() || s_[i_] != '"') fail("expected object key");
@@ -127,11 +130,13 @@ private:
                 v->obj[k] = value();
             } while (eat(','));
             expect('}');
+            --depth_;
         } else if (c == '[') {
             ++i_; v->kind = JValue::Array;
-            if (eat(']')) return v;
+            if (eat(']')) { --depth_; return v; }
             do { v->arr.push_back(value()); } while (eat(','));
             expect(']');
+            --depth_;
         } else if (c == '"') {
             v->kind = JValue::String; v->str = string();
         } else if (!s_.compare(i_, 4, "true")) { i_ += 4; v->kind = JValue::Bool; v->b = true;

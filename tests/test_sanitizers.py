@@ -1,0 +1,52 @@
+"""ASan + UBSan over the code that runs on the CPU: the host C++ scene/JSON/request reader and the
+oracle.  GPU AddressSanitizer is not available on the pool, so device code is covered by the bit-exact parity tests."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+
+
+def _sanitizers_work(tmp_path):
+    src = tmp_path / "probe.c"
+    src.write_text("int main(void){return 0;}\n")
+    exe = tmp_path / "probe"
+    r = subprocess.run(["gcc", *SAN, str(src), "-o", str(exe)], capture_output=True)
+    return r.returncode == 0 and subprocess.run([str(exe)], env=ENV).returncode == 0
+
+
+def test_host_json_reader_under_asan_ubsan(pkg, tmp_path):
+    if not _sanitizers_work(tmp_path):
+        pytest.skip("libasan/libubsan not usable in this environment")
+    exe = tmp_path / "host_json"
+    subprocess.check_call(["g++", "-std=c++17", "-ffp-contract=off", *SAN, os.path.join(ROOT, "tests", "sanitize", "host_json_main.cpp"),
+                           os.path.join(ROOT, "optix-test-smallpt_amd", "host", "scene.cpp"), "-o", str(exe)])
+    good = pkg.spheres_to_json(pkg.random_spheres(64, 3), camera={"origin": [1, 2, 3], "direction": [0, 0, -1], "fov": 0.5, "push": 1})
+    texts = [good, good[:-1], good[:len(good) // 2], "", "{", "[]", '{"spheres": 3}', '{"spheres": [{"radius": 1}]}',
+             '{"spheres": [{"radius": "x", "center": [1,2,3], "emission": [0,0,0], "color": [1,1,1], "refl": "DIFF"}]}',
+             '{"spheres": [], "camera": {"origin": [1, 2]}}', '{"action": "update_camera", "org": [0, -0.99, 0]}',
+             '{"action": "update_camera", "org": [0, "a", 0]}', '{"a": "\\u12', '{"a": "\\', "nul", "-", '{"spheres": [' * 2000,
+             '{"spheres": [], "x": "' + "\\n" * 5000 + '"}']
+    files = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"in{i}.json"
+        p.write_text(t)
+        files.append(str(p))
+    r = subprocess.run([str(exe), *files], capture_output=True, text=True, env=ENV)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "scenes ok 2" in r.stdout          # the well-formed scene and the empty-spheres one
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    if not _sanitizers_work(tmp_path):
+        pytest.skip("libasan/libubsan not usable in this environment")
+    exe = tmp_path / "oracle_san"
+    subprocess.check_call(["gcc", "-std=c11", "-ffp-contract=off", "-fno-fast-math", *SAN,
+                           os.path.join(ROOT, "tests", "sanitize", "oracle_main.c"), os.path.join(ROOT, "oracle", "smallpt_oracle.c"),
+                           "-lm", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "oracle sanitizer run ok" in r.stdout
