@@ -13,8 +13,9 @@
  *   int cpuRender(argc, argv) (smallpt.cpp:269-379): the        spt_render()           (host image)
  *     offline render; and Vector<float3> Renderer::render(..)   spt_render_rows_device() (row band,
  *     (smallpt.cpp:679-680,692-814), sole caller :922             device-resident, async)
- *   Intersector::traceRays + shadePaths per bounce              inside the megakernel; not exposed
- *     (smallpt.cpp:553-587,154-267)
+ *   Intersector::traceRays + shadePaths per bounce              inside the kernels; the triangle seam itself
+ *     (smallpt.cpp:553-587,154-267)                               (addTriangleMesh/build/traceRays, :427-473) is
+ *                                                                 spt_set_meshes() / spt_trace_rays()
  *   accumBuffer += outImage under accumBufferMutex and the      spt_progressive_begin / _frame / _snapshot / _end
  *     GL thread's copy of it (smallpt.cpp:881-883,924-940,       (accumulation buffer resident in HBM)
  *     955-959)
@@ -102,6 +103,31 @@ int  spt_device_count(void);
 
 /* Uploads the sphere table (replaces the global spheres[] + materials vector, smallpt.cpp:31-50,288-290). */
 int  spt_set_scene(spt_ctx* ctx, const spt_sphere* spheres, uint32_t n);
+
+/* ---- triangle meshes: the reference's Intersector seam (smallpt.cpp:427-473 CPUIntersector, :475-603 OptixIntersector) ----
+ * TriMesh (scene.h:6-15), Material (scene.h:66-73), Ray (scene.h:58-62), Hit (scene.h:31-43; dist = 1e20 on a miss). */
+typedef struct spt_mesh {
+    const float*    positions;   /* positionBuffer: nverts x 3 */
+    const float*    normals;     /* normalBuffer:   nverts x 3 */
+    const uint32_t* indices;     /* indexBuffer:    ntris x 3  */
+    uint32_t nverts, ntris;
+} spt_mesh;
+typedef struct spt_material { float emission[3]; float color[3]; int32_t refl; uint32_t pad; } spt_material;
+typedef struct spt_ray { float o[3]; float d[3]; } spt_ray;
+typedef struct spt_hit { float dist; uint32_t instId; uint32_t triId; float x[3]; float n[3]; float uv[2]; } spt_hit;
+
+/* Intersector::addTriangleMesh for every mesh + build() (smallpt.cpp:437-447 / :489-530): uploads the instances
+ * (materials[i] belongs to mesh i, :170) and makes the mesh scene current: spt_render* then trace it with the reference's
+ * triangle arithmetic (triIntersect scene.cpp:52-70, intersect :95-116, makeHit :73-93; hit.n is the interpolated,
+ * un-normalised vertex normal).  spt_set_scene switches back to spheres. */
+int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
+/* Vector<Hit> Intersector::traceRays(const PathContrib*, size_t) (smallpt.cpp:460-470, :553-587): closest hit of n rays
+ * against the current mesh scene; host buffers in and out like the reference's RTP_BUFFER_TYPE_HOST queries (:571-575). */
+int  spt_trace_rays(spt_ctx* ctx, const spt_ray* rays, uint64_t n, spt_hit* hits);
+/* Host-only helper: makeSphereTriMesh(origin, radius, subdivLongitude) (scene.cpp:3-48): fills (L+1)(2L+1) positions and
+ * normals and 4L^2 triangles (L = subdiv_longitude, default 32 at scene.h:17); returns the triangle count. */
+uint32_t spt_make_sphere_trimesh(const float origin[3], float radius, uint32_t subdiv_longitude,
+                                 float* positions, float* normals, uint32_t* indices);
 
 /* Host-only helper: the camera constants of cpuRender for a w x h image (smallpt.cpp:277-279). */
 int  spt_camera_smallpt(uint32_t w, uint32_t h, spt_camera* out);

@@ -3,12 +3,12 @@ Celeborn2BeAlive/optix-test-smallpt.  The compute path is the gfx950 megakernel 
 include/smallpt_mi355x.h (csrc/); this package is the thin host-side mirror of the reference's
 scene structs and render entry points.  Import name: ``optix_test_smallpt_amd`` (see the shim at
 the repository root)."""
-from ._lib import (INTERNAL_SYMBOLS, LIB_PATH, MULTI_SYMBOLS, SYMBOLS, SptCamera, SptMultiStats, SptSphere, SptStats,  # noqa: F401
+from ._lib import (INTERNAL_SYMBOLS, LIB_PATH, MULTI_SYMBOLS, SYMBOLS, SptCamera, SptMaterial, SptMesh, SptMultiStats, SptSphere, SptStats,  # noqa: F401
                    load_library, load_multi_library)
 from .renderer import (FLAG_NORMALISE, MultiRenderer, ProgressiveRenderer, Renderer, SptError, pinhole_camera,  # noqa: F401
                        smallpt_camera, to_int, write_ppm)
-from .scene import (DIFF, REFR, SPEC, SPHERE_DTYPE, cornell9, make_spheres, random_spheres,  # noqa: F401
-                    spheres_from_json, spheres_to_json)
+from .scene import (DIFF, HIT_DTYPE, RAY_DTYPE, REFR, SPEC, SPHERE_DTYPE, TriMesh, cornell9, make_sphere_trimesh,  # noqa: F401
+                    make_spheres, random_spheres, single_triangle_scene, spheres_from_json, spheres_to_json)
 
 __all__ = ["Renderer", "MultiRenderer", "ProgressiveRenderer", "SptError", "smallpt_camera", "pinhole_camera", "cornell9", "random_spheres", "make_spheres",
            "spheres_from_json", "spheres_to_json", "SPHERE_DTYPE", "DIFF", "SPEC", "REFR",

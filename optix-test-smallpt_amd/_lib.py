@@ -27,6 +27,15 @@ class SptStats(C.Structure):
                 ("grid_blocks", C.c_uint32), ("block_threads", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class SptMesh(C.Structure):          # TriMesh, scene.h:6-15
+    _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("indices", C.c_void_p),
+                ("nverts", C.c_uint32), ("ntris", C.c_uint32)]
+
+
+class SptMaterial(C.Structure):      # Material, scene.h:66-73
+    _fields_ = [("emission", C.c_float * 3), ("color", C.c_float * 3), ("refl", C.c_int32), ("pad", C.c_uint32)]
+
+
 # every symbol include/smallpt_mi355x.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -36,6 +45,9 @@ SYMBOLS = {
     "spt_api_version": (C.c_int, []),
     "spt_device_count": (C.c_int, []),
     "spt_set_scene": (C.c_int, [_P, _P, C.c_uint32]),
+    "spt_set_meshes": (C.c_int, [_P, C.POINTER(SptMesh), C.c_uint32, C.POINTER(SptMaterial)]),
+    "spt_trace_rays": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "spt_make_sphere_trimesh": (C.c_uint32, [C.c_float * 3, C.c_float, C.c_uint32, _P, _P, _P]),
     "spt_camera_smallpt": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(SptCamera)]),
     "spt_camera_pinhole": (C.c_int, [C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float, C.POINTER(SptCamera)]),
     "spt_render": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,

@@ -48,6 +48,10 @@ struct spt_ctx {
     float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
     size_t stack_cap = 0;          // in floats
     bool last_was_pool = false;
+    // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
+    bool mesh_scene = false;
+    float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
+    uint32_t ntris = 0, ninst = 0;
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
     float* d_frame = nullptr;
     uint32_t prog_w = 0, prog_h = 0;
@@ -152,6 +156,11 @@ void spt_destroy(spt_ctx* c)
     if (c->d_stack) (void)hipFree(c->d_stack);
     if (c->d_accum) (void)hipFree(c->d_accum);
     if (c->d_frame) (void)hipFree(c->d_frame);
+    if (c->d_tris) (void)hipFree(c->d_tris);
+    if (c->d_tri_index) (void)hipFree(c->d_tri_index);
+    if (c->d_verts) (void)hipFree(c->d_verts);
+    if (c->d_inst_first) (void)hipFree(c->d_inst_first);
+    if (c->d_mesh_mats) (void)hipFree(c->d_mesh_mats);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -209,6 +218,7 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
     SPT_HIP(c, hipMemcpy(c->d_geom, geom.data(), sizeof(float4) * cap, hipMemcpyHostToDevice));
     SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
     c->n = n;
+    c->mesh_scene = false;
     // The un-guarded sqrt fix-up in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
     // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
     c->needs_guard = false;
@@ -223,6 +233,146 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
     for (uint32_t i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k)
             if (!(s[i].color[k] >= 0.f && s[i].color[k] <= 1.f) || !(std::fabs(s[i].emission[k]) <= 3e38f)) c->pool_ok = false;
+    return 0;
+}
+
+// ---- triangle meshes (smallpt.cpp:427-473, scene.cpp:3-116) ----
+namespace {
+inline HostF3 hsub(HostF3 a, HostF3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline HostF3 hld(const float* p) { return {p[0], p[1], p[2]}; }
+// material rows as for spheres: {emission, refl | emissive << 2} {color, pmax} {color * (1/pmax), 0}
+inline void material_rows(const float e[3], const float col[3], int32_t refl, float4* rows)
+{
+    const float pmax = std::fmax(std::fmax(col[0], col[1]), col[2]);     // smallpt.cpp:177
+    const float inv = 1.0f / pmax;                                       // :192
+    const bool emissive = !(e[0] == 0.f && e[1] == 0.f && e[2] == 0.f);
+    const int32_t rb = refl | (emissive ? 4 : 0);
+    float reflbits;
+    std::memcpy(&reflbits, &rb, 4);
+    rows[0] = make_float4(e[0], e[1], e[2], reflbits);
+    rows[1] = make_float4(col[0], col[1], col[2], pmax);
+    rows[2] = make_float4(col[0] * inv, col[1] * inv, col[2] * inv, 0.0f);
+}
+}  // namespace
+
+uint32_t spt_make_sphere_trimesh(const float origin[3], float radius, uint32_t subdiv_longitude, float* positions, float* normals, uint32_t* indices)
+{
+    if (!origin || !positions || !normals || !indices || subdiv_longitude == 0) return 0;
+    const uint32_t discLong = subdiv_longitude, discLat = 2 * discLong;                 // scene.cpp:5-6
+    const float pi = 3.14159265358979323846f, half_pi = 1.57079632679489661923f;        // maths.h:14-15
+    const float rcpLat = 1.f / discLat, rcpLong = 1.f / discLong;                       // :8
+    const float dPhi = pi * 2.f * rcpLat, dTheta = pi * rcpLong;                        // :9
+    uint32_t nv = 0;
+    for (uint32_t j = 0; j <= discLong; ++j) {                                          // :13
+        const float cosTheta = std::cos(-half_pi + j * dTheta);                         // :15 (float overloads)
+        const float sinTheta = std::sin(-half_pi + j * dTheta);                         // :16
+        for (uint32_t i = 0; i <= discLat; ++i) {                                       // :18
+            const float cx = std::sin(i * dPhi) * cosTheta, cy = sinTheta, cz = std::cos(i * dPhi) * cosTheta;   // :19-23
+            positions[3 * nv + 0] = origin[0] + radius * cx;                            // :25
+            positions[3 * nv + 1] = origin[1] + radius * cy;
+            positions[3 * nv + 2] = origin[2] + radius * cz;
+            normals[3 * nv + 0] = cx; normals[3 * nv + 1] = cy; normals[3 * nv + 2] = cz;   // :26
+            ++nv;
+        }
+    }
+    uint32_t ni = 0;
+    for (uint32_t j = 0; j < discLong; ++j) {                                           // :32
+        const uint32_t offset = j * (discLat + 1);
+        for (uint32_t i = 0; i < discLat; ++i) {
+            indices[ni++] = offset + i; indices[ni++] = offset + (i + 1); indices[ni++] = offset + discLat + 1 + (i + 1);          // :37-39
+            indices[ni++] = offset + i; indices[ni++] = offset + discLat + 1 + (i + 1); indices[ni++] = offset + i + discLat + 1;  // :41-43
+        }
+    }
+    return ni / 3;
+}
+
+int spt_set_meshes(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials)
+{
+    if (!c) return 1;
+    if (nmesh && (!meshes || !materials)) return c->fail("spt_set_meshes: NULL argument");
+    uint64_t ntris = 0, nverts = 0;
+    for (uint32_t i = 0; i < nmesh; ++i) {
+        const spt_mesh& m = meshes[i];
+        if ((m.ntris && !m.indices) || (m.nverts && (!m.positions || !m.normals))) return c->fail("spt_set_meshes: mesh %u has NULL buffers", i);
+        if (materials[i].refl < SPT_DIFF || materials[i].refl > SPT_REFR) return c->fail("spt_set_meshes: material %u has refl=%d", i, materials[i].refl);
+        for (uint64_t k = 0; k < (uint64_t)m.ntris * 3; ++k)
+            if (m.indices[k] >= m.nverts) return c->fail("spt_set_meshes: mesh %u index %u out of range (%u vertices)", i, m.indices[k], m.nverts);
+        ntris += m.ntris; nverts += m.nverts;
+    }
+    if (ntris > 0x7FFFFFFFull || nverts > 0x7FFFFFFFull) return c->fail("spt_set_meshes: too many triangles");
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    // flatten: triangle records with the per-call constants of triIntersect (scene.cpp:56-60) evaluated once
+    std::vector<float4> tris(3 * (size_t)(ntris ? ntris : 1)), verts(2 * (size_t)(nverts ? nverts : 1)), mats(3 * (size_t)(nmesh ? nmesh : 1));
+    std::vector<uint4> tidx((size_t)(ntris ? ntris : 1));
+    std::vector<uint32_t> first((size_t)nmesh + 1, 0u);
+    size_t t = 0, vbase = 0;
+    for (uint32_t i = 0; i < nmesh; ++i) {
+        const spt_mesh& m = meshes[i];
+        first[i] = (uint32_t)t;
+        for (uint32_t v = 0; v < m.nverts; ++v) {
+            verts[2 * (vbase + v)] = make_float4(m.positions[3 * v], m.positions[3 * v + 1], m.positions[3 * v + 2], 0.f);
+            verts[2 * (vbase + v) + 1] = make_float4(m.normals[3 * v], m.normals[3 * v + 1], m.normals[3 * v + 2], 0.f);
+        }
+        for (uint32_t k = 0; k < m.ntris; ++k, ++t) {
+            const uint32_t i1 = m.indices[3 * k], i2 = m.indices[3 * k + 1], i3 = m.indices[3 * k + 2];
+            const HostF3 v0 = hld(m.positions + 3 * i1), v1 = hld(m.positions + 3 * i2), v2 = hld(m.positions + 3 * i3);
+            const HostF3 e1 = hsub(v1, v0), e2 = hsub(v2, v0);                          // scene.cpp:56-57
+            const HostF3 n = hcross(e1, e2);                                            // :60
+            tris[3 * t] = make_float4(v0.x, v0.y, v0.z, n.x);
+            tris[3 * t + 1] = make_float4(e1.x, e1.y, e1.z, n.y);
+            tris[3 * t + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
+            tidx[t] = make_uint4((uint32_t)vbase + i1, (uint32_t)vbase + i2, (uint32_t)vbase + i3, i);
+        }
+        vbase += m.nverts;
+        material_rows(materials[i].emission, materials[i].color, materials[i].refl, &mats[3 * (size_t)i]);
+    }
+    first[nmesh] = (uint32_t)t;
+    auto upload = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
+        if (dptr) (void)hipFree(dptr);
+        dptr = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dptr), bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    SPT_HIP(c, upload(c->d_tris, tris.data(), tris.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_tri_index, tidx.data(), tidx.size() * sizeof(uint4)));
+    SPT_HIP(c, upload(c->d_verts, verts.data(), verts.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_inst_first, first.data(), first.size() * sizeof(uint32_t)));
+    SPT_HIP(c, upload(c->d_mesh_mats, mats.data(), mats.size() * sizeof(float4)));
+    c->ntris = (uint32_t)ntris; c->ninst = nmesh;
+    c->mesh_scene = true;
+    return 0;
+}
+
+static spt::MParams mesh_params(const spt_ctx* c)
+{
+    spt::MParams M{};
+    M.tris = c->d_tris; M.tri_index = c->d_tri_index; M.verts = c->d_verts; M.inst_first_tri = c->d_inst_first; M.mats = c->d_mesh_mats;
+    M.ntris = c->ntris; M.ninst = c->ninst;
+    return M;
+}
+
+int spt_trace_rays(spt_ctx* c, const spt_ray* rays, uint64_t n, spt_hit* hits)
+{
+    if (!c) return 1;
+    if (!c->mesh_scene) return c->fail("spt_trace_rays: no mesh scene set (call spt_set_meshes)");
+    if (n == 0) return 0;
+    if (!rays || !hits) return c->fail("spt_trace_rays: NULL argument");
+    if (n > 0x7FFFFFFFull * 256ull) return c->fail("spt_trace_rays: too many rays for one call");
+    static_assert(sizeof(spt_ray) == 24 && sizeof(spt_hit) == 44, "Ray / Hit layouts of scene.h");
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) { SPT_HIP(c, hipEventSynchronize(c->ev_stop)); }
+    float *d_rays = nullptr, *d_hits = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(spt_ray));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_hits), n * sizeof(spt_hit));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * sizeof(spt_ray), hipMemcpyHostToDevice, c->stream);
+    const spt::MParams M = mesh_params(c);
+    if (e == hipSuccess) e = spt_mesh_trace_rays(&M, d_rays, n, d_hits, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(spt_hit), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rays); (void)hipFree(d_hits);
+    if (e != hipSuccess) return c->fail("spt_trace_rays: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -273,7 +423,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     const uint32_t nb_log2 = samps >= 128u ? 3u : (samps >= 64u ? 2u : (samps >= 32u ? 1u : 0u));
     const uint32_t nb = 1u << nb_log2;
     if (npix * 4 * nb > 0xF0000000ull) return c->fail("spt_render_rows_device: band has more than 15*2^26 sample blocks (%u per pixel); split it", 4u * nb);
-    if (!c->d_geom) return c->fail("spt_render_rows_device: no scene set (call spt_set_scene)");
+    if (!c->d_geom && !c->mesh_scene) return c->fail("spt_render_rows_device: no scene set (call spt_set_scene)");
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) { SPT_HIP(c, hipEventSynchronize(c->ev_stop)); }
 
@@ -307,6 +457,37 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
                                     std::fmax(std::fabs(cam->origin[2]), std::fabs(cam->push)));
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
+
+    // ---- triangle-mesh scene (spt_mesh.hip): brute-force closest hit with the reference's triangle arithmetic ----
+    if (c->mesh_scene) {
+        uint64_t blocks = (uint64_t)c->cu_count * (c->blocks_per_cu ? c->blocks_per_cu : 4u);
+        const uint64_t needed = (ntasks + 255) / 256;
+        if (blocks > needed) blocks = needed;
+        if (blocks < 1) blocks = 1;
+        const size_t need_stack = spt_mesh_stack_floats((uint32_t)blocks);
+        if (need_stack > c->stack_cap) {
+            if (c->d_stack) (void)hipFree(c->d_stack);
+            c->d_stack = nullptr; c->stack_cap = 0;
+            SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_stack), need_stack * sizeof(float)));
+            c->stack_cap = need_stack;
+        }
+        P.stack = c->d_stack;
+        P.n = 0; P.n_pad = 1; P.geom = nullptr; P.mat = nullptr;
+        const spt::MParams M = mesh_params(c);
+        SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
+        SPT_HIP(c, hipEventRecord(c->ev_start, st));
+        SPT_HIP(c, spt_mesh_launch(&P, &M, (uint32_t)blocks, st));
+        SPT_HIP(c, hipEventRecord(c->ev_mid, st));
+        SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
+        SPT_HIP(c, hipEventRecord(c->ev_stop, st));
+        c->pending = true;
+        c->last_was_pool = false;
+        c->last = spt_stats{};
+        c->last.samples = npix * 4ull * samps;
+        c->last.grid_blocks = (uint32_t)blocks;
+        c->last.block_threads = 256;
+        return 0;
+    }
 
     // ---- material-sorted pool kernel (spt_pool.hip): small tables, regular scenes; variant bit 10 forces the megakernel ----
     if (c->pool_ok && cam_big <= 1e15f && !(c->variant & 0x500u)) {

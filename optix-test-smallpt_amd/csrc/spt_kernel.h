@@ -37,8 +37,22 @@ struct KParams {
     unsigned long long watchdog_ticks;  // s_memtime ticks after which a wave gives up (0 = never)
 };
 
+// Triangle-mesh scene (spt_mesh.hip): the reference's TriMesh instances flattened into device tables
+struct MParams {
+    const float4* tris;            // ntris x 3: {v0.xyz, n.x} {v1-v0, n.y} {v2-v0, n.z}, n = cross(v1-v0, v2-v0) (scene.cpp:56-60)
+    const uint4* tri_index;        // ntris x {i1, i2, i3 (global vertex ids), instance}
+    const float4* verts;           // nverts x 2: {position, 0} {normal, 0}
+    const uint32_t* inst_first_tri;// first global triangle of every instance
+    const float4* mats;            // 3 rows per instance, as for spheres
+    uint32_t ntris, ninst;
+};
+
 }  // namespace spt
 
+extern "C" size_t spt_mesh_lds_bytes(void);
+extern "C" size_t spt_mesh_stack_floats(uint32_t blocks);
+extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_rays, uint64_t nrays, float* d_hits, hipStream_t stream);
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block);
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream);
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream);

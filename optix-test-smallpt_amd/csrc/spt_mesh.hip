@@ -1,0 +1,314 @@
+// spt_mesh.hip -- triangle-mesh primitives of the reference on gfx950 (MI355X): the Intersector seam
+// (addTriangleMesh / build / traceRays, smallpt.cpp:427-473; the OptiX Prime variant :475-603 is what it replaces) and
+// the path tracer over a mesh scene.
+//
+//   * triIntersect (scene.cpp:52-70), intersect(ro, rd, mesh) (scene.cpp:95-116), CPUIntersector::intersect
+//     (smallpt.cpp:443-458) and makeHit(instId, mesh, meshHit) (scene.cpp:73-93) with exactly their arithmetic: the
+//     per-triangle constants v0, v1-v0, v2-v0 and n = cross(v1-v0, v2-v0) are evaluated once on the host (the same single
+//     IEEE operations the reference repeats per call); d = 1.0 / dot(rd, n) -- a double division rounded to float in the
+//     reference -- equals the correctly rounded binary32 reciprocal for every input (a double-rounding slip would need
+//     x * m = 1 with a 25-bit m, i.e. x a power of two, where both are exact), so it is rcp_exact(|x|) with the sign restored.
+//   * closest hit = brute force over all triangles of all instances in (instance, triangle) order with strict '<' and
+//     dist > 0, which is what the per-mesh loop + the per-instance loop of the reference select.  Triangle records
+//     (48 B) are staged through LDS in tiles by the whole workgroup and read back wave-uniformly (broadcast).
+//   * meshkernel: one lane = one path, one task = one D9 sample block of a jitter cell, same RNG / accumulation order /
+//     shading decisions (D1-D19) as the sphere kernels; hit.n is the interpolated, un-normalised vertex normal exactly
+//     as makeHit returns it.  This is the reference's actual direction of travel (OptiX triangles); an LDS/BVH traversal
+//     kernel is what comes next, the brute-force loop is the correctness anchor.
+#include "spt_device.h"
+#include "spt_kernel.h"
+
+namespace spt {
+
+constexpr int kMeshBlock = 256;
+constexpr int kTile = 768;                                       // triangles per LDS tile: 768 x 48 B = 36 KB
+constexpr uint32_t kMeshInfKey = 0x60AD78ECu - 1u;               // key of 1e20f (maths.h:16); key(t) = bits(t) - 1
+
+__device__ __forceinline__ uint32_t lane_id_m() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// 1.0 / x of scene.cpp:62 (see the header): correctly rounded reciprocal with the sign handled outside the fast path
+__device__ __forceinline__ float rcp_signed(float x)
+{
+    const float r = rcp_exact<true>(__builtin_fabsf(x));
+    return __uint_as_float(__float_as_uint(r) | (__float_as_uint(x) & 0x80000000u));
+}
+
+// triIntersect against one staged triangle record; returns t (1e20 when the barycentrics reject it) and u, v
+__device__ __forceinline__ float tri_test(const float4 r0, const float4 r1, const float4 r2, f3 ro, f3 rd, float& u, float& v)
+{
+    const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z), n = mk(r0.w, r1.w, r2.w);
+    const f3 rov0 = ro - v0;                                                     // :58
+    const f3 q = cross(rov0, rd);                                                // :61
+    const float d = rcp_signed(dot(rd, n));                                      // :62
+    u = d * dot(neg(q), e2);                                                     // :63
+    v = d * dot(q, e1);                                                          // :64
+    float t = d * dot(neg(n), rov0);                                             // :65
+    if (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) t = 1e20f;           // :67
+    return t;
+}
+
+// Closest hit over every triangle (see the header).  All threads of the workgroup must call this together (the tiles are
+// staged cooperatively); `active` lanes trace their ray.  Returns the global triangle index or 0xFFFFFFFF.
+__device__ __forceinline__ uint32_t closest_triangle(const float4* __restrict__ tris, uint32_t ntris, float4* s_tile,
+                                                     bool active, f3 ro, f3 rd, float& t_out)
+{
+    uint32_t near_key = kMeshInfKey, near_tri = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < ntris; base += kTile) {
+        const uint32_t cnt = ntris - base < (uint32_t)kTile ? ntris - base : (uint32_t)kTile;
+        __syncthreads();                                       // the previous tile is no longer read
+        for (uint32_t i = threadIdx.x; i < 3u * cnt; i += blockDim.x) s_tile[i] = tris[3u * (size_t)base + i];
+        __syncthreads();
+        if (active) {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                float u, v;
+                const float t = tri_test(s_tile[3 * k], s_tile[3 * k + 1], s_tile[3 * k + 2], ro, rd, u, v);
+                // "t > 0 && t < nearest" (scene.cpp:105, smallpt.cpp:449) as one unsigned compare on key = bits(t) - 1:
+                // +0 wraps to the top, negative and NaN keys lie above the key of 1e20
+                const uint32_t key = __float_as_uint(t) - 1u;
+                if (key < near_key) { near_key = key; near_tri = base + k; }
+            }
+        }
+    }
+    t_out = __uint_as_float(near_key + 1u);
+    return near_tri;
+}
+
+struct MeshHit { float dist; uint32_t inst, tri; f3 x, n; float u, v; };
+
+// makeHit(instId, mesh, meshHit), scene.cpp:73-93, for the winning triangle (u, v re-evaluated from its record)
+__device__ __forceinline__ MeshHit make_hit(const MParams& M, uint32_t tri, float t, f3 ro, f3 rd)
+{
+    MeshHit h;
+    float u, v;
+    (void)tri_test(M.tris[3 * (size_t)tri], M.tris[3 * (size_t)tri + 1], M.tris[3 * (size_t)tri + 2], ro, rd, u, v);
+    const uint4 ix = M.tri_index[tri];                                           // {i1, i2, i3 (global vertex ids), instance}
+    const float w = 1.f - u - v;                                                 // :82
+    const float4 p1 = M.verts[2 * (size_t)ix.x], p2 = M.verts[2 * (size_t)ix.y], p3 = M.verts[2 * (size_t)ix.z];
+    const float4 n1 = M.verts[2 * (size_t)ix.x + 1], n2 = M.verts[2 * (size_t)ix.y + 1], n3 = M.verts[2 * (size_t)ix.z + 1];
+    h.x = mk(p1.x, p1.y, p1.z) * w + mk(p2.x, p2.y, p2.z) * u + mk(p3.x, p3.y, p3.z) * v;   // :88
+    h.n = mk(n1.x, n1.y, n1.z) * w + mk(n2.x, n2.y, n2.z) * u + mk(n3.x, n3.y, n3.z) * v;   // :89
+    h.dist = t; h.inst = ix.w; h.tri = tri - M.inst_first_tri[ix.w]; h.u = u; h.v = v;
+    return h;
+}
+
+// Intersector::traceRays (smallpt.cpp:460-470 / :553-587): one Hit (scene.h:31-43, 44 bytes) per ray.
+__global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const float* __restrict__ rays, uint64_t nrays, float* __restrict__ hits)
+{
+    extern __shared__ float4 s_tile[];
+    const uint64_t i = (uint64_t)blockIdx.x * kMeshBlock + threadIdx.x;
+    const bool active = i < nrays;
+    f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    if (active) { ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]); rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]); }
+    float t;
+    const uint32_t tri = closest_triangle(M.tris, M.ntris, s_tile, active, ro, rd, t);
+    if (!active) return;
+    float* h = hits + 11 * i;
+    if (tri == 0xFFFFFFFFu) {                                                    // Hit{}: dist = inf (smallpt.cpp:454-455)
+        h[0] = 1e20f;
+        for (int k = 1; k < 11; ++k) h[k] = 0.f;
+        return;
+    }
+    const MeshHit m = make_hit(M, tri, t, ro, rd);
+    h[0] = m.dist; h[1] = __uint_as_float(m.inst); h[2] = __uint_as_float(m.tri);
+    h[3] = m.x.x; h[4] = m.x.y; h[5] = m.x.z; h[6] = m.n.x; h[7] = m.n.y; h[8] = m.n.z; h[9] = m.u; h[10] = m.v;
+}
+
+// ---- path tracer over the mesh scene ------------------------------------------------------------------------------
+struct MPath { f3 o, d, w; uint32_t depth, branch, rbase; };
+
+__global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const MParams M)
+{
+    extern __shared__ float4 s_tile[];
+    const uint32_t lane = lane_id_m();
+    const uint32_t gthread = blockIdx.x * kMeshBlock + threadIdx.x;
+    float* const gstack = K.stack + (size_t)gthread * (3 * 12);                  // 3 pending children x 12 words per thread
+    const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
+    const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
+    const f3 cam_cx = mk(K.cam_cx[0], K.cam_cx[1], K.cam_cx[2]);
+    const f3 cam_cy = mk(K.cam_cy[0], K.cam_cy[1], K.cam_cy[2]);
+
+    bool alive = false, task_valid = false, queue_empty = false;
+    uint32_t task = 0, sp = 0, s_gen = 0, s_end = 0, px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
+    MPath p{mk(0, 0, 0), mk(0, 0, 1), mk(0, 0, 0), 0u, 0u, 0u};
+    f3 acc = mk(0, 0, 0);
+    unsigned long long nbounce = 0, nkill = 0;
+
+    for (;;) {
+        // ---- continue the lane's task: pending transmitted child, next sample of the block, or a new task ----
+        if (!alive && sp > 0) {
+            --sp;
+            const float* e = gstack + sp * 12;
+            p.o = mk(e[0], e[1], e[2]); p.d = mk(e[3], e[4], e[5]); p.w = mk(e[6], e[7], e[8]);
+            const uint32_t db = __float_as_uint(e[9]);
+            p.depth = db & 0xFFFFu; p.branch = db >> 16;
+            p.rbase = rng_base(k0, p.branch, p.depth);
+            alive = true;
+        }
+        if (!alive && s_gen == s_end && !queue_empty) {
+            if (task_valid) K.cells[task] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            task = atomicAdd(K.queue, 1u);                    // the triangle loop dwarfs this atomic
+            task_valid = task < K.ntasks;
+            if (task_valid) {
+                const uint32_t cellid = task >> K.nb_log2, blk = task & ((1u << K.nb_log2) - 1u);
+                const uint32_t pix_local = cellid >> 2;
+                cell = cellid & 3u;
+                const uint32_t ry = pix_local / K.w;
+                px = pix_local - ry * K.w; py = K.row_begin + ry;
+                const uint32_t pixel_idx = py * K.w + px;                        // GLOBAL index (smallpt.cpp:298)
+                p0 = mix32(pixel_idx + K.s0); p1 = mix32(pixel_idx ^ K.s1);
+                s_gen = blk * K.sb;
+                s_end = s_gen + K.sb < K.samps ? s_gen + K.sb : K.samps;
+                acc = mk(0, 0, 0);
+            } else {
+                queue_empty = true; s_gen = s_end = 0;
+            }
+        }
+        if (!alive && task_valid && s_gen < s_end) {
+            // camera ray of sample s_gen (smallpt.cpp:325-340 / :745-760), as in spt_kernel.hip phase C1
+            const uint32_t index_in_pixel = cell * K.samps + s_gen;              // :306
+            k0 = mix32(p0 ^ (index_in_pixel * kGolden));
+            k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
+            const float u1 = rng_draw(k0 + ((1u << 28) | 0u) * kGolden, k1);
+            const float u2 = rng_draw(k0 + ((1u << 28) | 1u) * kGolden, k1);
+            const uint32_t sx = cell & 1u, sy = cell >> 1;
+            float ax, ay;
+            if (K.sampler == 0u) {
+                const float r1 = 2 * u1;
+                const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
+                const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
+                const float r2 = 2 * u2;
+                const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
+                const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
+                const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
+                const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
+                const double qx0 = tx * K.inv_w, qy0 = ty * K.inv_h;
+                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)K.w, tx), K.inv_w, qx0);
+                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)K.h, ty), K.inv_h, qy0);
+                ax = (float)(qx - .5); ay = (float)(qy - .5);
+            } else {
+                const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;
+                const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);
+                const float nx = (((float)px + 0.5f) + fx) * K.inv_wf;
+                const float ny = (((float)py + 0.5f) + fy) * K.inv_hf;
+                ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;
+            }
+            const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
+            const float inv = rcp_exact(sqrt_exact(dot(dd, dd)));
+            p.o = cam_o + dd * K.cam_push;
+            p.d = dd * inv;
+            p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; p.rbase = k0;
+            ++s_gen;
+            alive = true;
+        }
+        if (!__syncthreads_or(alive ? 1 : 0)) break;           // no lane of the workgroup has work left
+
+        // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
+        float t;
+        const uint32_t tri = closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
+        if (alive) {
+            ++nbounce;
+            if (tri == 0xFFFFFFFFu) {
+                alive = false;                                                   // smallpt.cpp:168 miss (D13)
+            } else {
+                // ---- shadePaths, smallpt.cpp:170-263 under D2-D6, D18, D19 ----
+                const MeshHit h = make_hit(M, tri, t, p.o, p.d);
+                const float4 me = M.mats[3 * h.inst + 0], mc = M.mats[3 * h.inst + 1];
+                const int refl = __float_as_int(me.w) & 3;
+                const f3 n = h.n;                                                // :173, un-normalised
+                const f3 nl = dot(n, p.d) < 0 ? n : neg(n);                      // :174 (D2)
+                f3 f = mk(mc.x, mc.y, mc.z);                                     // :175
+                acc = acc + p.w * mk(me.x, me.y, me.z);                          // :179 (D4)
+                bool cont = true;
+                if (p.depth > 5) {                                               // :188 (D5)
+                    if (rng_draw(p.rbase, k1) < mc.w) { const float4 mf = M.mats[3 * h.inst + 2]; f = mk(mf.x, mf.y, mf.z); }
+                    else cont = false;
+                }
+                if (cont) {
+                    const f3 off = nl * 0.02f;                                   // :172 (D3)
+                    f3 no = h.x + off, nd, nf = f;
+                    if (refl == 0) {                                             // DIFF :208-215
+                        const uint32_t u1bits = rng_draw_bits(p.rbase + kGolden, k1);
+                        const float r2 = rng_draw(p.rbase + 2u * kGolden, k1);
+                        const float r2s = sqrt_exact(r2);
+                        float sn, cs;
+                        sincos2pi_bits(u1bits, sn, cs);                          // D17
+                        const f3 ww = nl;
+                        const bool ay = __builtin_fabsf(ww.x) >= 0.1f;          // (double)fabs(w.x) > .1, :211
+                        // cross((0,1,0), w) = (w.z, 0, -w.x); cross((1,0,0), w) = (0, -w.z, w.y): products with the axis' zeros only
+                        // add signed zeros that never reach a non-zero value or a comparison
+                        const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
+                        const f3 uu = normalize<true>(ur);
+                        const f3 vv = cross(ww, uu);
+                        nd = normalize<true>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_exact(1 - r2));   // :212
+                    } else {
+                        nd = p.d - n * 2.0f * dot(n, p.d);                       // :218 reflRay
+                        if (refl == 2) {                                         // REFR :225-263
+                            const bool into = dot(n, nl) > 0;
+                            const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;
+                            const float ddn = dot(p.d, nl);
+                            const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
+                            if (!(cos2t < 0)) {
+                                const f3 tdir = normalize<true>(p.d * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t))));
+                                const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);
+                                const float cc = 1 - (into ? -ddn : dot(tdir, n));
+                                const float c2 = cc * cc;
+                                const float Re = R0 + (1 - R0) * c2 * c2 * cc;
+                                const float Tr = 1 - Re;
+                                const f3 xin = h.x - off;
+                                if (p.depth <= 2) {                              // :248 split (D6)
+                                    const f3 tw = p.w * (f * Tr);
+                                    if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
+                                        float* e = gstack + sp * 12;
+                                        e[0] = xin.x; e[1] = xin.y; e[2] = xin.z; e[3] = tdir.x; e[4] = tdir.y; e[5] = tdir.z;
+                                        e[6] = tw.x; e[7] = tw.y; e[8] = tw.z;
+                                        e[9] = __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16));
+                                        ++sp;
+                                    }
+                                    nf = f * Re;
+                                } else {
+                                    const float Pr = 0.25f + 0.5f * Re;
+                                    const bool pick_refl = rng_draw(p.rbase + kGolden, k1) < Pr;
+                                    const float inv = rcp_exact(pick_refl ? Pr : 1.f - Pr);
+                                    nf = f * (pick_refl ? Re : Tr) * inv;
+                                    if (!pick_refl) { no = xin; nd = tdir; }
+                                }
+                            }
+                        }
+                    }
+                    // extend() smallpt.cpp:120-123 + D18 + D19
+                    p.w = p.w * nf;
+                    p.o = no; p.d = nd;
+                    ++p.depth;
+                    p.rbase += 4u * kGolden;
+                    if (p.depth >= SPT_K_MAX_DEPTH) { ++nkill; cont = false; }
+                    else cont = !(p.w.x == 0.f && p.w.y == 0.f && p.w.z == 0.f);
+                }
+                alive = cont;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { nbounce += __shfl_down(nbounce, off); nkill += __shfl_down(nkill, off); }
+    if (lane == 0) {
+        atomicAdd(&K.counters[0], nbounce);
+        if (nkill) atomicAdd(&K.counters[1], nkill);
+    }
+}
+
+}  // namespace spt
+
+extern "C" size_t spt_mesh_lds_bytes(void) { return (size_t)spt::kTile * 48u; }
+extern "C" size_t spt_mesh_stack_floats(uint32_t blocks) { return (size_t)blocks * spt::kMeshBlock * 36u; }
+
+extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream)
+{
+    const size_t lds = spt_mesh_lds_bytes();
+    hipLaunchKernelGGL(spt::meshkernel, dim3(blocks), dim3(spt::kMeshBlock), lds, stream, *K, *M);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_rays, uint64_t nrays, float* d_hits, hipStream_t stream)
+{
+    const uint64_t blocks = (nrays + spt::kMeshBlock - 1) / spt::kMeshBlock;
+    hipLaunchKernelGGL(spt::trace_rays, dim3((unsigned)blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(), stream, *M, d_rays, nrays, d_hits);
+    return hipGetLastError();
+}

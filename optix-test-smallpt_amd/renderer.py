@@ -9,8 +9,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import SptCamera, SptMultiStats, SptStats, load_library, load_multi_library
-from .scene import SPHERE_DTYPE
+from ._lib import SptCamera, SptMaterial, SptMesh, SptMultiStats, SptStats, load_library, load_multi_library
+from .scene import HIT_DTYPE, RAY_DTYPE, SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
 
@@ -88,6 +88,31 @@ class Renderer:
         spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
         self._scene = spheres
         self._check(self._lib.spt_set_scene(self._h, spheres.ctypes.data_as(C.c_void_p), len(spheres)))
+
+    def set_meshes(self, meshes, materials):
+        """Intersector::addTriangleMesh for every TriMesh + build() (smallpt.cpp:437-447); materials[i] = (emission, color,
+        refl) of instance i (smallpt.cpp:170).  Makes the mesh scene current for render()."""
+        ms = (SptMesh * max(1, len(meshes)))()
+        mats = (SptMaterial * max(1, len(meshes)))()
+        self._mesh_keepalive = list(meshes)
+        for i, (m, (e, col, refl)) in enumerate(zip(meshes, materials)):
+            ms[i].positions = m.positions.ctypes.data
+            ms[i].normals = m.normals.ctypes.data
+            ms[i].indices = m.indices.ctypes.data
+            ms[i].nverts, ms[i].ntris = len(m.positions), len(m.indices)
+            mats[i].emission = (C.c_float * 3)(*[float(v) for v in e])
+            mats[i].color = (C.c_float * 3)(*[float(v) for v in col])
+            mats[i].refl = int(refl)
+        self._check(self._lib.spt_set_meshes(self._h, ms, len(meshes), mats))
+
+    def trace_rays(self, rays):
+        """Intersector::traceRays (smallpt.cpp:460-470): rays = array of RAY_DTYPE (or (n, 6) floats); returns HIT_DTYPE[n]."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6) if not (hasattr(rays, "dtype") and rays.dtype == RAY_DTYPE) else rays
+        rays = np.ascontiguousarray(rays)
+        n = len(rays)
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        self._check(self._lib.spt_trace_rays(self._h, rays.ctypes.data_as(C.c_void_p), n, hits.ctypes.data_as(C.c_void_p)))
+        return hits
 
     def set_tuning(self, blocks_per_cu=0, variant=0):
         self._check(self._lib.spt_set_tuning(self._h, blocks_per_cu, variant))

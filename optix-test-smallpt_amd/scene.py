@@ -101,3 +101,44 @@ def spheres_from_json(text):
         refl = REFL_IDS[refl] if isinstance(refl, str) else int(refl)
         rows.append((s["radius"], s["center"], s["emission"], s["color"], refl))
     return make_spheres(rows), doc.get("camera")
+
+
+# ---- triangle meshes (scene.h:6-15 TriMesh, scene.cpp:3-48 makeSphereTriMesh) ----
+HIT_DTYPE = np.dtype([("dist", "<f4"), ("instId", "<u4"), ("triId", "<u4"), ("x", "<f4", 3), ("n", "<f4", 3), ("uv", "<f4", 2)])   # Hit, scene.h:31-43
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3)])                                                                           # Ray, scene.h:58-62
+assert HIT_DTYPE.itemsize == 44 and RAY_DTYPE.itemsize == 24
+
+
+class TriMesh:
+    """positionBuffer / normalBuffer / indexBuffer of the reference's TriMesh as contiguous numpy arrays."""
+
+    def __init__(self, positions, normals, indices):
+        self.positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        self.normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        assert len(self.positions) == len(self.normals)
+
+    @property
+    def triangle_count(self):          # TriMesh::triangleCount, scene.h:11-14
+        return len(self.indices)
+
+
+def make_sphere_trimesh(origin, radius, subdiv_longitude=32):
+    """makeSphereTriMesh(origin, radius, subdivLongitude = 32) (scene.cpp:3-48, scene.h:17) through the library's host
+    helper (the reference generates the table on the host with the C library's float cos/sin)."""
+    import ctypes as C
+    from ._lib import load_library
+    n = int(subdiv_longitude)
+    pos = np.zeros(((n + 1) * (2 * n + 1), 3), dtype=np.float32)
+    nor = np.zeros_like(pos)
+    idx = np.zeros((4 * n * n, 3), dtype=np.uint32)
+    nt = load_library().spt_make_sphere_trimesh((C.c_float * 3)(*[float(v) for v in origin]), float(radius), n,
+                                                pos.ctypes.data_as(C.c_void_p), nor.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p))
+    assert nt == len(idx)
+    return TriMesh(pos, nor, idx)
+
+
+def single_triangle_scene():
+    """SingleTriangleScene of the reference's main() (smallpt.cpp:818-832): one triangle, material emission (1,0,0), DIFF."""
+    mesh = TriMesh([(-0.5, -0.5, -2), (0.5, -0.5, -2), (0, 0.5, -2)], [(1, 0, 0), (0, 1, 0), (0, 0, 1)], [(0, 1, 2)])
+    return [mesh], [((1, 0, 0), (0, 0, 0), DIFF)]

@@ -190,21 +190,121 @@ int orc_intersect_global_spheres(const orc_sphere* s, uint32_t n, const float o[
     return id;
 }
 
-/* scene.cpp:52-70 triIntersect.  The reference uses double literals 1.0/0.0 here: d is computed
- * as (float)(1.0 / (double)dot). Fixture only. */
+/* scene.cpp:52-70 triIntersect.  The reference uses double literals here: d = 1.0 / dot(rd, n) is a double division
+ * rounded to float by the assignment, and the comparisons u < 0.0 ... promote to double (same truth values). */
+static inline float tri_intersect(f3 ro, f3 rd, f3 v0, f3 v1, f3 v2, float* u_, float* v_)
+{
+    f3 v1v0 = sub(v1, v0), v2v0 = sub(v2, v0), rov0 = sub(ro, v0);   /* :56-58 */
+    f3 n = cross(v1v0, v2v0);                                        /* :60 */
+    f3 q = cross(rov0, rd);                                          /* :61 */
+    float d = (float)(1.0 / (double)dot(rd, n));                     /* :62 */
+    float u = d * dot(scl(q, -1.0f), v2v0);                          /* :63 */
+    float v = d * dot(q, v1v0);                                      /* :64 */
+    float t = d * dot(scl(n, -1.0f), rov0);                          /* :65 */
+    if (u < 0.0 || u > 1.0 || v < 0.0 || (u + v) > 1.0) t = ORC_INF; /* :67 */
+    *u_ = u; *v_ = v;
+    return t;
+}
+
 void orc_tri_intersect(const float ro_[3], const float rd_[3], const float v0_[3], const float v1_[3],
                        const float v2_[3], float* t_, float* u_, float* v_)
 {
-    f3 ro = ld(ro_), rd = ld(rd_), v0 = ld(v0_), v1 = ld(v1_), v2 = ld(v2_);
-    f3 v1v0 = sub(v1, v0), v2v0 = sub(v2, v0), rov0 = sub(ro, v0);
-    f3 n = cross(v1v0, v2v0);
-    f3 q = cross(rov0, rd);
-    float d = (float)(1.0 / (double)dot(rd, n));
-    float u = d * dot(scl(q, -1.0f), v2v0);
-    float v = d * dot(q, v1v0);
-    float t = d * dot(scl(n, -1.0f), rov0);
-    if (u < 0.0 || u > 1.0 || v < 0.0 || (u + v) > 1.0) t = ORC_INF;
-    *t_ = t; *u_ = u; *v_ = v;
+    *t_ = tri_intersect(ld(ro_), ld(rd_), ld(v0_), ld(v1_), ld(v2_), u_, v_);
+}
+
+/* scene.cpp:3-48 makeSphereTriMesh (subdivLongitude default 32, scene.h:17): (discLong+1)*(discLat+1) vertices with
+ * discLat = 2*discLong, 2*discLong*discLat triangles.  cos/sin are the C++ float overloads (cosf/sinf of the C library:
+ * host-side table generation, not on the device path).  Buffers are caller-allocated; returns the triangle count. */
+uint32_t orc_make_sphere_trimesh(const float origin[3], float radius, uint32_t subdiv_longitude,
+                                 float* positions, float* normals, uint32_t* indices)
+{
+    const uint32_t discLong = subdiv_longitude, discLat = 2 * discLong;        /* :5-6 */
+    const float pi = 3.14159265358979323846f, half_pi = 1.57079632679489661923f; /* M_PIf, M_PI_2f (maths.h:14-15) */
+    const float rcpLat = 1.f / discLat, rcpLong = 1.f / discLong;              /* :8 */
+    const float dPhi = pi * 2.f * rcpLat, dTheta = pi * rcpLong;               /* :9 */
+    uint32_t nv = 0;
+    for (uint32_t j = 0; j <= discLong; ++j) {                                 /* :13 */
+        const float cosTheta = cosf(-half_pi + j * dTheta);                    /* :15 */
+        const float sinTheta = sinf(-half_pi + j * dTheta);                    /* :16 */
+        for (uint32_t i = 0; i <= discLat; ++i) {                              /* :18 */
+            const f3 coords = mk(sinf(i * dPhi) * cosTheta, sinTheta, cosf(i * dPhi) * cosTheta);   /* :19-23 */
+            st(positions + 3 * nv, add(ld(origin), scl(coords, radius)));      /* :25 origin + radius * coords */
+            st(normals + 3 * nv, coords);                                      /* :26 */
+            ++nv;
+        }
+    }
+    uint32_t ni = 0;
+    for (uint32_t j = 0; j < discLong; ++j) {                                  /* :32 */
+        const uint32_t offset = j * (discLat + 1);                             /* :34 */
+        for (uint32_t i = 0; i < discLat; ++i) {                               /* :35 */
+            indices[ni++] = offset + i;                                        /* :37-39 */
+            indices[ni++] = offset + (i + 1);
+            indices[ni++] = offset + discLat + 1 + (i + 1);
+            indices[ni++] = offset + i;                                        /* :41-43 */
+            indices[ni++] = offset + discLat + 1 + (i + 1);
+            indices[ni++] = offset + i + discLat + 1;
+        }
+    }
+    return ni / 3;
+}
+
+/* scene.cpp:95-116 intersect(ro, rd, mesh): brute force over the triangles, nearest dist > 0, strict '<' (lowest
+ * triangle index wins ties); returns the triangle index or -1 and the barycentrics of the winner. */
+static inline int intersect_mesh(const orc_mesh* m, f3 ro, f3 rd, float* dist, float* u, float* v)
+{
+    float minDistance = 3.402823466e+38f;                                      /* :97 numeric_limits<float>::max() */
+    int minIdx = -1;
+    float mu = 0, mv = 0;
+    for (uint32_t i = 0; i < m->ntris; ++i) {                                  /* :100 */
+        const uint32_t i1 = m->indices[3 * i], i2 = m->indices[3 * i + 1], i3 = m->indices[3 * i + 2];   /* :101-103 */
+        float tu, tv;
+        const float t = tri_intersect(ro, rd, ld(m->positions + 3 * i1), ld(m->positions + 3 * i2), ld(m->positions + 3 * i3), &tu, &tv);
+        if (t > 0 && t < minDistance) {                                        /* :105 */
+            minDistance = t; minIdx = (int)i; mu = tu; mv = tv;                /* :106-108 */
+        }
+    }
+    if (minDistance <= 0.f || minDistance == 3.402823466e+38f) return -1;      /* :112-113: MeshHit{} (dist = inf) */
+    *dist = minDistance; *u = mu; *v = mv;
+    return minIdx;
+}
+
+/* CPUIntersector::intersect (smallpt.cpp:443-458) + makeHit(instId, mesh, meshHit) (scene.cpp:73-93): nearest mesh hit
+ * over the instances in order, strict '<'; x and n interpolated as w*A + u*B + v*C with w = 1 - u - v (the reference's
+ * barycentric convention, smallpt.cpp:544-546); n is NOT normalised (scene.cpp:90).  A triangle hit at dist >= inf
+ * (1e20) is a miss like MeshHit{} (:455).  Returns the instance index or -1. */
+static inline int intersect_meshes(const orc_mesh* meshes, uint32_t nmesh, f3 ro, f3 rd, orc_hit* hit)
+{
+    float nearest = ORC_INF;                                                   /* MeshHit{}: dist = inf */
+    int inst = -1, tri = -1;
+    float nu = 0, nv = 0;
+    for (uint32_t i = 0; i < nmesh; ++i) {                                     /* :447 */
+        float t, u, v;
+        const int k = intersect_mesh(&meshes[i], ro, rd, &t, &u, &v);          /* :448 */
+        if (k >= 0 && t > 0.f && t < nearest) {                                /* :449 */
+            nearest = t; inst = (int)i; tri = k; nu = u; nv = v;               /* :450-451 */
+        }
+    }
+    hit->dist = ORC_INF; hit->instId = 0; hit->triId = 0;
+    st(hit->x, mk(0, 0, 0)); st(hit->n, mk(0, 0, 0)); hit->uv[0] = hit->uv[1] = 0;
+    if (nearest == ORC_INF) return -1;                                         /* :454-455 */
+    const orc_mesh* m = &meshes[inst];
+    const float w = 1.f - nu - nv;                                             /* scene.cpp:82 */
+    const uint32_t i1 = m->indices[3 * tri], i2 = m->indices[3 * tri + 1], i3 = m->indices[3 * tri + 2];   /* :84-86 */
+    hit->dist = nearest; hit->instId = (uint32_t)inst; hit->triId = (uint32_t)tri;   /* :76-78 */
+    st(hit->x, add(add(scl(ld(m->positions + 3 * i1), w), scl(ld(m->positions + 3 * i2), nu)), scl(ld(m->positions + 3 * i3), nv)));   /* :88 */
+    st(hit->n, add(add(scl(ld(m->normals + 3 * i1), w), scl(ld(m->normals + 3 * i2), nu)), scl(ld(m->normals + 3 * i3), nv)));       /* :89 */
+    hit->uv[0] = nu; hit->uv[1] = nv;                                          /* :90 */
+    return inst;
+}
+
+/* Intersector::traceRays (smallpt.cpp:460-470): one Hit per ray. */
+void orc_trace_rays(const orc_mesh* meshes, uint32_t nmesh, const orc_ray* rays, uint64_t n, orc_hit* hits)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+        intersect_meshes(meshes, nmesh, ld(rays[i].o), ld(rays[i].d), &hits[i]);
 }
 
 /* ---------------------------------------------------------------- camera ------------------ */
@@ -286,8 +386,11 @@ typedef struct {
 } path_t;
 
 typedef struct {
-    const orc_sphere* sph;
+    const orc_sphere* sph;       /* sphere scene (analytic primitives, D1) ... */
     uint32_t n;
+    const orc_mesh* meshes;      /* ... or a triangle-mesh scene (the reference's Intersector seam): one material per instance */
+    const orc_material* mats;
+    uint32_t nmesh;
     int zero_cut;
     uint64_t bounces;
     uint64_t depth_kills;
@@ -316,13 +419,26 @@ static void trace_sample(trace_ctx* tc, path_t cam_path, uint32_t k0, uint32_t k
     while (sp > 0) {
         path_t p = stack[--sp];
         for (;;) {
-            /* ---- intersectGlobalSpheres, smallpt.cpp:352 -> :144-152 -> :54-70 ---- */
+            /* ---- intersectGlobalSpheres, smallpt.cpp:352 -> :144-152 -> :54-70; or Intersector::traceRays :782 ---- */
             float dist; f3 hx, n;
             tc->bounces++;
-            int id = intersect_global_spheres(tc->sph, tc->n, p.o, p.d, &dist, &hx, &n);
-            if (id < 0) break;                                 /* :168 miss => black (D13) */
+            int id;
+            orc_material mesh_mat;
+            const orc_material* m;
+            if (tc->meshes) {
+                orc_hit hit;
+                id = intersect_meshes(tc->meshes, tc->nmesh, p.o, p.d, &hit);
+                if (id < 0) break;                             /* :168 */
+                hx = ld(hit.x); n = ld(hit.n);                 /* :172-173: the interpolated, un-normalised mesh normal */
+                mesh_mat = tc->mats[id];                       /* :170 materials[hit.instId] */
+                m = &mesh_mat;
+            } else {
+                id = intersect_global_spheres(tc->sph, tc->n, p.o, p.d, &dist, &hx, &n);
+                if (id < 0) break;                             /* :168 miss => black (D13) */
+                /* the material fields of orc_sphere from `emission` on have the layout of orc_material */
+                m = (const orc_material*)tc->sph[id].emission;
+            }
             /* ---- shadePaths body, smallpt.cpp:170-263 ---- */
-            const orc_sphere* m = &tc->sph[id];                /* :170 */
             f3 nl = dot(n, p.d) < 0 ? n : scl(n, -1.0f);       /* :174 with the flip (D2) */
             f3 f = ld(m->color);                               /* :175 */
             const float pmax = fmaxf(fmaxf(f.x, f.y), f.z);    /* :177 optix::fmaxf(float3) */
@@ -430,12 +546,34 @@ void orc_sample_blocks(uint32_t samps, uint32_t* nb, uint32_t* sb)
  * (orc_sample_blocks); inside a block every emission event is added to the block accumulator in (sample-ascending,
  * DFS pre-order) order; cell = ((B0 + B1) + B2) + ... in block order; pixel = ((c0 + c1) + c2) + c3.
  * (Up to 31 samples per cell there is one block: the classic per-subpixel accumulator of smallpt.) */
+static int render_scene(const orc_sphere* spheres, uint32_t n, const orc_mesh* meshes, uint32_t nmesh, const orc_material* mats,
+                        const orc_camera* cam, uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+                        uint32_t samps, uint64_t seed, uint32_t flags, int threads, float* out, orc_stats* stats);
+
 int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
                uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
                uint32_t samps, uint64_t seed, uint32_t flags, int threads,
                float* out, orc_stats* stats)
 {
-    if (!cam || !out || (!spheres && n) || w == 0 || h == 0 || samps == 0) return 1;
+    if (!spheres && n) return 1;
+    return render_scene(spheres, n, NULL, 0, NULL, cam, w, h, row_begin, row_count, samps, seed, flags, threads, out, stats);
+}
+
+/* The same render over a triangle-mesh scene: closest hit = CPUIntersector (smallpt.cpp:427-473), material = materials[instId]. */
+int orc_render_meshes(const orc_mesh* meshes, uint32_t nmesh, const orc_material* materials, const orc_camera* cam,
+                      uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+                      uint32_t samps, uint64_t seed, uint32_t flags, int threads, float* out, orc_stats* stats)
+{
+    static const orc_mesh none = {0, 0, 0, 0, 0};
+    if (nmesh && (!meshes || !materials)) return 1;
+    return render_scene(NULL, 0, meshes ? meshes : &none, nmesh, materials, cam, w, h, row_begin, row_count, samps, seed, flags, threads, out, stats);
+}
+
+static int render_scene(const orc_sphere* spheres, uint32_t n, const orc_mesh* meshes, uint32_t nmesh, const orc_material* mats,
+                        const orc_camera* cam, uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+                        uint32_t samps, uint64_t seed, uint32_t flags, int threads, float* out, orc_stats* stats)
+{
+    if (!cam || !out || w == 0 || h == 0 || samps == 0) return 1;
     if ((uint64_t)w * h > 0xFFFFFFFFull) return 1;
     if ((uint64_t)row_begin + row_count > h) return 1;
     if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return 1;
@@ -452,7 +590,7 @@ int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
 #endif
     for (int64_t pi = 0; pi < npix; ++pi) {
         trace_ctx tc;
-        tc.sph = spheres; tc.n = n; tc.zero_cut = !(flags & ORC_FLAG_NO_ZERO_WEIGHT_CUT);
+        tc.sph = spheres; tc.n = n; tc.meshes = meshes; tc.nmesh = nmesh; tc.mats = mats; tc.zero_cut = !(flags & ORC_FLAG_NO_ZERO_WEIGHT_CUT);
         tc.bounces = 0; tc.depth_kills = 0;
         const uint32_t r = (uint32_t)(pi / w);
         const uint32_t px = (uint32_t)(pi - (int64_t)r * w);                    /* :296 */

@@ -45,6 +45,26 @@ typedef struct {
                             sampleRay pinhole (smallpt.cpp:745-760,626-641) */
 } orc_camera;
 
+/* Material, scene.h:66-73 (emission, color, refl) + padding: the tail of orc_sphere from `emission` on has this layout. */
+typedef struct {
+    float   emission[3];
+    float   color[3];
+    int32_t refl;
+    uint32_t pad;
+} orc_material;
+
+/* TriMesh, scene.h:6-15: positionBuffer / normalBuffer (nverts x 3 floats), indexBuffer (ntris x 3). */
+typedef struct {
+    const float*    positions;
+    const float*    normals;
+    const uint32_t* indices;
+    uint32_t nverts, ntris;
+} orc_mesh;
+
+typedef struct { float o[3], d[3]; } orc_ray;              /* Ray, scene.h:58-62 */
+/* Hit, scene.h:31-43 (44 bytes): dist = 1e20 (inf, maths.h:16) on a miss */
+typedef struct { float dist; uint32_t instId, triId; float x[3], n[3], uv[2]; } orc_hit;
+
 typedef struct {
     uint64_t samples;    /* camera paths started                   */
     uint64_t bounces;    /* intersectGlobalSpheres() calls executed */
@@ -65,9 +85,15 @@ void  orc_make_hit_normal(const orc_sphere* s, const float x[3], float n[3]);
 /* smallpt.cpp:54-70; returns sphere index or -1; writes dist, x, n */
 int   orc_intersect_global_spheres(const orc_sphere* s, uint32_t n, const float o[3], const float d[3],
                                    float* dist, float x[3], float nrm[3]);
-/* scene.cpp:52-70 triIntersect (fixture only; triangles are out of scope for the HIP path) */
+/* scene.cpp:52-70 triIntersect */
 void  orc_tri_intersect(const float ro[3], const float rd[3], const float v0[3], const float v1[3],
                         const float v2[3], float* t, float* u, float* v);
+/* scene.cpp:3-48 makeSphereTriMesh: fills (L+1)(2L+1) positions/normals and 4L^2 triangles (L = subdiv_longitude);
+ * returns the triangle count */
+uint32_t orc_make_sphere_trimesh(const float origin[3], float radius, uint32_t subdiv_longitude,
+                                 float* positions, float* normals, uint32_t* indices);
+/* Intersector::traceRays (smallpt.cpp:427-473: CPUIntersector::intersect = scene.cpp:95-116 per mesh + makeHit :73-93) */
+void  orc_trace_rays(const orc_mesh* meshes, uint32_t nmesh, const orc_ray* rays, uint64_t n, orc_hit* hits);
 /* D7 counter-based RNG */
 uint32_t orc_mix32(uint32_t x);
 void  orc_sample_keys(uint64_t seed, uint32_t pixel_idx, uint32_t sample_idx, uint32_t* k0, uint32_t* k1);
@@ -96,6 +122,12 @@ int orc_render(const orc_sphere* spheres, uint32_t n, const orc_camera* cam,
                uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
                uint32_t samps_per_cell, uint64_t seed, uint32_t flags, int threads,
                float* out, orc_stats* stats);
+
+/* The same render over a triangle-mesh scene (materials[i] belongs to mesh instance i, smallpt.cpp:170). */
+int orc_render_meshes(const orc_mesh* meshes, uint32_t nmesh, const orc_material* materials, const orc_camera* cam,
+                      uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+                      uint32_t samps_per_cell, uint64_t seed, uint32_t flags, int threads,
+                      float* out, orc_stats* stats);
 
 int orc_num_threads(void);
 

@@ -1,0 +1,95 @@
+"""f4: the reference's triangle-mesh primitives (TriMesh, makeSphereTriMesh scene.cpp:3-48, triIntersect :52-70,
+intersect(mesh) :95-116, makeHit(mesh) :73-93) and the Intersector seam (addTriangleMesh/build/traceRays,
+smallpt.cpp:427-473).  CPU part: the oracle restatement against the SURVEY.md 8(c) known answers and the host
+tessellator against the oracle's.  GPU part: spt_trace_rays and the mesh path tracer bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+
+def test_make_sphere_trimesh_counts_and_host_equals_oracle(pkg, oracle):
+    """KAT: makeSphereTriMesh(0, 1) => 2145 vertices, 2145 normals, 12288 indices, 4096 triangles."""
+    m = pkg.make_sphere_trimesh((0, 0, 0), 1.0)
+    assert m.positions.shape == (2145, 3) and m.normals.shape == (2145, 3) and m.indices.size == 12288 and m.triangle_count == 4096
+    pos, nor, idx = oracle.make_sphere_trimesh((0, 0, 0), 1.0)
+    assert np.array_equal(m.positions, pos) and np.array_equal(m.normals, nor) and np.array_equal(m.indices, idx)
+    assert np.abs(np.linalg.norm(m.normals, axis=1) - 1).max() < 1e-6 and int(m.indices.max()) == 2144
+    m2 = pkg.make_sphere_trimesh((27, 16.5, 47), 16.5, 8)
+    pos, nor, idx = oracle.make_sphere_trimesh((27, 16.5, 47), 16.5, 8)
+    assert np.array_equal(m2.positions, pos) and np.array_equal(m2.indices, idx) and m2.triangle_count == 4 * 8 * 8
+    assert np.array_equal(m2.positions, (np.float32(16.5) * nor + np.array((27, 16.5, 47), dtype=np.float32)))     # origin + radius * coords, :25
+
+
+def test_oracle_trace_rays_single_triangle_kats(pkg, oracle):
+    """KAT: triangle of smallpt.cpp:826, ro=(0,0,0), rd=(0,0,-1) => t=2, u=.25, v=.5; ro=(2,0,0) => miss 1e20.
+    makeHit: x = (1-u-v)A + uB + vC, n likewise from the vertex normals (1,0,0),(0,1,0),(0,0,1) => n = (w, u, v)."""
+    meshes, _ = pkg.single_triangle_scene()
+    hits = oracle.trace_rays(meshes, [[0, 0, 0, 0, 0, -1], [2, 0, 0, 0, 0, -1], [0, 0, -4, 0, 0, 1], [0, 0, 0, 0, 0, 1]])
+    h = hits[0]
+    assert h["dist"] == 2.0 and tuple(h["uv"]) == (0.25, 0.5) and h["instId"] == 0 and h["triId"] == 0
+    assert tuple(h["x"]) == (0.0, 0.0, -2.0) and tuple(h["n"]) == (0.25, 0.25, 0.5)       # the barycentric convention of :544-546
+    assert hits[1]["dist"] == np.float32(1e20) and hits[3]["dist"] == np.float32(1e20)    # beside / behind
+    assert hits[2]["dist"] == 2.0                                                         # hit from the back side: no culling
+
+
+def _mesh_scene(pkg):
+    """Tessellated counterparts of a small Cornell-like set-up: floor + light as coarse sphere meshes, a diffuse, a mirror
+    and a glass ball, and the single triangle; few enough triangles for the oracle's brute force."""
+    S = pkg.make_sphere_trimesh
+    meshes = [S((0, -1e3 - 2, -6), 1e3, 24), S((0, 40, -6), 30.0, 8), S((-2.2, -1, -6), 1.0, 8), S((0, -1, -7.5), 1.0, 8),
+              S((2.2, -1, -5.5), 1.0, 8), pkg.single_triangle_scene()[0][0]]
+    mats = [((0, 0, 0), (.7, .7, .7), pkg.DIFF), ((3, 3, 3), (0, 0, 0), pkg.DIFF), ((0, 0, 0), (.75, .25, .25), pkg.DIFF),
+            ((0, 0, 0), (.999, .999, .999), pkg.SPEC), ((0, 0, 0), (.999, .999, .999), pkg.REFR), ((1, 0, 0), (0, 0, 0), pkg.DIFF)]
+    return meshes, mats
+
+
+@pytest.mark.gpu
+def test_trace_rays_matches_oracle(pkg, renderer, oracle):
+    """The Intersector seam on the GPU: Hit{dist, instId, triId, x, n, uv} of every ray equals the oracle's, bit for bit."""
+    meshes, mats = _mesh_scene(pkg)
+    renderer.set_meshes(meshes, mats)
+    rs = np.random.RandomState(7)
+    n = 4000
+    o = np.tile(np.array([0, -1, 0], dtype=np.float32), (n, 1)) + rs.uniform(-.5, .5, (n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32) + np.array([0, 0, -2], dtype=np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([np.concatenate([o, d], axis=1),
+                           np.array([[0, 0, 0, 0, 0, -1], [2, 0, 0, 0, 0, -1], [0, -1, 0, 0, 1, 0], [0, -1, 0, 0, 0, 0]], dtype=np.float32)])
+    got = renderer.trace_rays(rays)
+    ref = oracle.trace_rays(meshes, rays)
+    assert got.tobytes() == ref.tobytes()
+    assert (got["dist"] < 1e20).sum() > n // 2 and len(set(got["instId"][got["dist"] < 1e20])) >= 4
+    k = len(rays) - 4
+    assert got[k]["dist"] == 2.0 and tuple(got[k]["uv"]) == (0.25, 0.5) and got[k]["instId"] == 5      # the KAT through the GPU
+    renderer.set_scene(pkg.cornell9())
+    with pytest.raises(pkg.SptError, match="no mesh scene"):
+        renderer.trace_rays(rays[:2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,samps,seed,pinhole", [(32, 18, 1, 0, True), (24, 20, 2, 3, False)])
+def test_mesh_path_tracer_matches_oracle(pkg, renderer, oracle, w, h, samps, seed, pinhole):
+    """The path tracer over triangle meshes (interpolated un-normalised normals, every material, glass split) against the
+    oracle's render over the same meshes."""
+    meshes, mats = _mesh_scene(pkg)
+    renderer.set_meshes(meshes, mats)
+    cam = pkg.pinhole_camera() if pinhole else None
+    img, st = renderer.render(w, h, samps, seed=seed, normalise=not pinhole, camera=cam)
+    ref, rst = oracle.render_meshes(meshes, mats, w, h, samps, seed=seed, normalise=not pinhole, camera=cam)
+    assert np.array_equal(img, ref), f"{int((img != ref).any(axis=-1).sum())} pixels differ"
+    assert st["bounces"] == rst["bounces"] and st["samples"] == rst["samples"]
+    if pinhole:
+        assert img.max() > 0
+    renderer.set_scene(pkg.cornell9())            # back to spheres for the other tests of the session
+
+
+@pytest.mark.gpu
+def test_single_triangle_scene_of_main(pkg, renderer, oracle):
+    """main()'s SingleTriangleScene (smallpt.cpp:818-838) under the viewer camera at 1280x720 / 8, one frame."""
+    meshes, mats = pkg.single_triangle_scene()
+    renderer.set_meshes(meshes, mats)
+    cam = pkg.pinhole_camera()
+    img, st = renderer.render(160, 90, 1, seed=0, normalise=False, camera=cam)
+    ref, rst = oracle.render_meshes(meshes, mats, 160, 90, 1, seed=0, normalise=False, camera=cam)
+    assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+    assert img[:, :, 0].max() > 0 and not img[:, :, 1:].any()        # the triangle emits pure red
+    renderer.set_scene(pkg.cornell9())
