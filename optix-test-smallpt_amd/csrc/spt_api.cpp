@@ -492,7 +492,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     // ---- material-sorted pool kernel (spt_pool.hip): small tables, regular scenes; variant bit 10 forces the megakernel ----
     if (c->pool_ok && cam_big <= 1e15f && !(c->variant & 0x500u)) {
         const uint32_t psel = (c->variant >> 11) & 3u;
-        const int pool = psel == 1 ? 96 : (psel == 2 ? 192 : (psel == 3 ? 128 : 160));   // default 160: four workgroups per CU, batches ~98 % full
+        const int pool = psel == 1 ? 96 : (psel == 2 ? 192 : (psel == 3 ? 128 : spt_pool_default_slots()));   // default: four workgroups per CU
         const size_t lds = spt_pool_lds_bytes(P.n, pool);
         uint32_t per_cu = c->blocks_per_cu;
         if (per_cu == 0) {

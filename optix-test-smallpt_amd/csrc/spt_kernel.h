@@ -63,5 +63,6 @@ extern "C" size_t spt_pool_lds_bytes(uint32_t n, int pool);
 extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool);
 extern "C" size_t spt_pool_state_bytes(uint32_t blocks, int pool);
 extern "C" int spt_pool_max_spheres(void);
+extern "C" int spt_pool_default_slots(void);
 extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, int pool, hipStream_t stream);
 extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream);

@@ -34,9 +34,13 @@ constexpr uint32_t kEpsBias = 0x38D1B717u + 1u;                  // bits(1e-4f) 
 constexpr uint32_t kInfKeyP = 0x60AD78ECu - kEpsBias;            // key of 1e20f
 constexpr int kPoolBlock = 256;
 constexpr uint32_t kNoTask = 0xFFFFFFFFu;
-constexpr int kStackWords = 12;                                  // o.xyz d.xyz w.xyz (depth|branch<<16) k0 k1
+constexpr int kStackWords = 12;                                  // one pending child = 3 float4: {o, depth|branch<<16} {d, k0} {w, k1}
 constexpr int kMaxUnroll = 24;                                   // spheres handled by the unrolled closest-hit code
-constexpr int kSlotBytes = 62;                                   // LDS per pool slot (layout in poolkernel)
+#ifndef SPT_POOL_TASK_LDS
+#define SPT_POOL_TASK_LDS 1                                      // {task id, next sample} of a slot in LDS (else in global memory)
+#endif
+constexpr bool kTaskLds = SPT_POOL_TASK_LDS != 0;
+constexpr int kSlotBytes = kTaskLds ? 70 : 62;                   // LDS per pool slot (layout in poolkernel)
 
 __device__ __forceinline__ uint32_t lane_id_p() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t rank_in(unsigned long long m)
@@ -63,7 +67,7 @@ enum { C_GEN = 0, C_DIFF = 1, C_REFR = 2 };
 template <int P, int NG>
 __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
 {
-    static_assert(P % 32 == 0 && P <= 256, "pool size");
+    static_assert(P % 16 == 0 && P <= 256, "pool size");
     extern __shared__ float4 lds[];
     constexpr int kWaveF4 = (kSlotBytes * P) / 16;               // float4 per wave region
     static_assert((kSlotBytes * P) % 16 == 0, "wave region must be float4-aligned");
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     float* const ACX = reinterpret_cast<float*>(A2 + P);         // block sum of the slot's task (D9), SoA
     float* const ACY = ACX + P;
     float* const ACZ = ACY + P;
-    uint8_t* const LG = reinterpret_cast<uint8_t*>(ACZ + P);     // GEN list
+    uint2* const TS = reinterpret_cast<uint2*>(ACZ + P);         // {task id, next sample} (LDS build)
+    uint8_t* const LG = reinterpret_cast<uint8_t*>(ACZ + P) + (kTaskLds ? 8 * P : 0);   // GEN list
     // LG[P .. 2P-1]: array shared by the DIFF list (from index 0 up) and the REFR list (from P-1 down)
     float4* const s_geom = lds + (kPoolBlock / 64) * kWaveF4;    // 3 NG x {c.xyz, r*r}
     float4* const s_mat = s_geom + 3 * NG;                       // 3 x (3 NG) material rows
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     }
     // every slot starts on the GEN list as a finished, task-less slot
     const uint32_t wave_gid = blockIdx.x * (kPoolBlock / 64) + wave;
-    uint2* const gtask = K.slot_state + (size_t)wave_gid * P;    // {task id, next sample} per slot
+    uint2* const gtask = kTaskLds ? TS : K.slot_state + (size_t)wave_gid * P;    // {task id, next sample} per slot
     for (uint32_t s = lane; s < (uint32_t)P; s += 64) {
         gtask[s] = make_uint2(kNoTask, 0u);
         A1[s].w = __uint_as_float(0u);                           // stack count 0
@@ -97,8 +102,9 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     }
     __syncthreads();
 
-    float* const gstack = K.stack + (size_t)wave_gid * (3 * kStackWords * P);
-    auto stack_at = [&](uint32_t e, int f, uint32_t slot) -> float& { return gstack[(e * kStackWords + f) * P + slot]; };
+    // pending transmitted children: [slot][entry] records of 48 contiguous bytes (one 64-byte line per push / pop)
+    float4* const gstack = reinterpret_cast<float4*>(K.stack) + (size_t)wave_gid * (3 * 3 * P);
+    auto stack_rec = [&](uint32_t e, uint32_t slot) -> float4* { return gstack + (slot * 3u + e) * 3u; };
 
     const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
     const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
@@ -165,13 +171,13 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             if (valid) {
                 if (sp > 0u) {                                   // pending transmitted child (reflected subtree is done)
                     --sp;
-                    o = mk(stack_at(sp, 0, slot), stack_at(sp, 1, slot), stack_at(sp, 2, slot));
-                    d = mk(stack_at(sp, 3, slot), stack_at(sp, 4, slot), stack_at(sp, 5, slot));
-                    w = mk(stack_at(sp, 6, slot), stack_at(sp, 7, slot), stack_at(sp, 8, slot));
-                    const uint32_t db = __float_as_uint(stack_at(sp, 9, slot));
+                    const float4* rec = stack_rec(sp, slot);
+                    const float4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
+                    o = mk(s0.x, s0.y, s0.z); d = mk(s1.x, s1.y, s1.z); w = mk(s2.x, s2.y, s2.z);
+                    const uint32_t db = __float_as_uint(s0.w);
                     depth = db & 0xFFFu; branchf = db >> 16;
-                    const uint32_t k0 = __float_as_uint(stack_at(sp, 10, slot));
-                    k1 = __float_as_uint(stack_at(sp, 11, slot));
+                    const uint32_t k0 = __float_as_uint(s1.w);
+                    k1 = __float_as_uint(s2.w);
                     rbase = rng_base(k0, branchf & 7u, depth);
                     has_ray = true;
                 } else if (snext == send) {
@@ -324,12 +330,10 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                         if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
                             const uint32_t br = branchf & 7u;
                             const bool nonfin = !(__builtin_fabsf(tw.x) < __builtin_inff() && __builtin_fabsf(tw.y) < __builtin_inff() && __builtin_fabsf(tw.z) < __builtin_inff());
-                            stack_at(sp, 0, slot) = xin.x; stack_at(sp, 1, slot) = xin.y; stack_at(sp, 2, slot) = xin.z;
-                            stack_at(sp, 3, slot) = tdir.x; stack_at(sp, 4, slot) = tdir.y; stack_at(sp, 5, slot) = tdir.z;
-                            stack_at(sp, 6, slot) = tw.x; stack_at(sp, 7, slot) = tw.y; stack_at(sp, 8, slot) = tw.z;
-                            stack_at(sp, 9, slot) = __uint_as_float((depth + 1u) | ((br | (1u << depth) | ((branchf & 8u) | (nonfin ? 8u : 0u))) << 16));
-                            stack_at(sp, 10, slot) = __uint_as_float(rbase - ((br << 29) | (depth << 2)) * kGolden);   // k0
-                            stack_at(sp, 11, slot) = __uint_as_float(k1);
+                            float4* rec = stack_rec(sp, slot);
+                            rec[0] = make_float4(xin.x, xin.y, xin.z, __uint_as_float((depth + 1u) | ((br | (1u << depth) | ((branchf & 8u) | (nonfin ? 8u : 0u))) << 16)));
+                            rec[1] = make_float4(tdir.x, tdir.y, tdir.z, __uint_as_float(rbase - ((br << 29) | (depth << 2)) * kGolden));   // k0
+                            rec[2] = make_float4(tw.x, tw.y, tw.z, __uint_as_float(k1));
                             ++sp;
                         }
                         nf = f * Re;
@@ -475,6 +479,8 @@ extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool)
 extern "C" size_t spt_pool_state_bytes(uint32_t blocks, int pool) { return (size_t)blocks * (spt::kPoolBlock / 64) * (size_t)pool * sizeof(uint2); }
 
 extern "C" int spt_pool_max_spheres(void) { return spt::kMaxUnroll; }
+// 160 slots per wave with the 62-byte slot, 144 with the 70-byte slot: four workgroups (16 waves) per CU either way
+extern "C" int spt_pool_default_slots(void) { return spt::kTaskLds ? 144 : 160; }
 
 template <int P, int NG>
 static hipError_t launch_pool(const spt::KParams* K, uint32_t blocks, size_t lds, hipStream_t stream)
@@ -506,6 +512,7 @@ extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, in
     const size_t lds = spt_pool_lds_bytes(K->n, pool);
     if (pool == 128) return launch_pool_ng<128>(K, blocks, lds, stream);
     if (pool == 160) return launch_pool_ng<160>(K, blocks, lds, stream);
+    if (pool == 144) return launch_pool_ng<144>(K, blocks, lds, stream);
 #ifdef SPT_POOL_SIZES
     if (pool == 96) return launch_pool_ng<96>(K, blocks, lds, stream);
     if (pool == 192) return launch_pool_ng<192>(K, blocks, lds, stream);

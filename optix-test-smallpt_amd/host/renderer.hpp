@@ -55,6 +55,32 @@ public:
     void progressiveSnapshot(std::vector<float3>& image) { check(spt_progressive_snapshot(ctx_, reinterpret_cast<float*>(image.data()))); }
     void progressiveEnd() { check(spt_progressive_end(ctx_)); }
 
+    // The Intersector seam of the reference (smallpt.cpp:427-473 CPUIntersector / :475-603 OptixIntersector):
+    //   addTriangleMesh(mesh) for every instance + build()  ->  setMeshes(meshes, materials)   (materials[i] <-> instance i, :170)
+    //   Vector<Hit> traceRays(const PathContrib*, size_t)    ->  traceRays(rays, n)
+    void setMeshes(const std::vector<TriMesh>& meshes, const std::vector<Material>& materials)
+    {
+        if (meshes.size() != materials.size()) throw std::runtime_error("setMeshes: one material per mesh instance");
+        std::vector<spt_mesh> ms(meshes.size());
+        std::vector<spt_material> mats(meshes.size());
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            ms[i].positions = reinterpret_cast<const float*>(meshes[i].positionBuffer.data());
+            ms[i].normals = reinterpret_cast<const float*>(meshes[i].normalBuffer.data());
+            ms[i].indices = meshes[i].indexBuffer.data();
+            ms[i].nverts = (uint32_t)meshes[i].positionBuffer.size();
+            ms[i].ntris = (uint32_t)meshes[i].triangleCount();
+            const Material& m = materials[i];
+            mats[i] = spt_material{{m.emission.x, m.emission.y, m.emission.z}, {m.color.x, m.color.y, m.color.z}, (int32_t)m.refl, 0u};
+        }
+        check(spt_set_meshes(ctx_, ms.data(), (uint32_t)ms.size(), mats.data()));
+    }
+    std::vector<Hit> traceRays(const Ray* rays, size_t n)
+    {
+        std::vector<Hit> hits(n);
+        check(spt_trace_rays(ctx_, reinterpret_cast<const spt_ray*>(rays), (uint64_t)n, reinterpret_cast<spt_hit*>(hits.data())));
+        return hits;
+    }
+
     const spt_stats& stats() const { return stats_; }
     spt_ctx* handle() { return ctx_; }
 

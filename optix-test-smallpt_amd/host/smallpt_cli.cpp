@@ -29,6 +29,7 @@ int main(int argc, char* argv[])
     int spp = 4, w = 256, h = 256, device = 0;       // smallpt.cpp:274-276 defaults
     unsigned long long seed = 0;
     std::string scene_path, out_path = "image.ppm", dump_path;
+    bool single_triangle = false;
     bool parse_only = false, viewer = false, threaded = false, self_exchange = false;
     int frames = 1, frames_after = 0;
     std::vector<int> devices;
@@ -54,6 +55,7 @@ int main(int argc, char* argv[])
                 return 0;
             } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
         }
+        else if (a == "--single-triangle") single_triangle = true;   // SingleTriangleScene of main(), smallpt.cpp:818-832
         else if (a == "--viewer") viewer = true;
         else if (a == "--threaded") threaded = true;
         else if (a == "--self-exchange") self_exchange = true;
@@ -81,7 +83,18 @@ int main(int argc, char* argv[])
         if (viewer) {
             // main() of the reference (smallpt.cpp:840-1005) without GLFW/GL: render thread + request queue + accumulation
             Renderer renderer(device);
-            renderer.setScene(scene.spheres);
+            if (single_triangle) {
+                TriMesh triangle;                                                     // smallpt.cpp:826-828
+                triangle.positionBuffer = {make_float3(-0.5f, -0.5f, -2), make_float3(0.5f, -0.5f, -2), make_float3(0, 0.5f, -2)};
+                triangle.normalBuffer = {make_float3(1, 0, 0), make_float3(0, 1, 0), make_float3(0, 0, 1)};
+                triangle.indexBuffer = {0, 1, 2};
+                renderer.setMeshes({triangle}, {Material{make_float3(1, 0, 0), make_float3(0, 0, 0), DIFF}});   // :821, :830-831
+                const Ray probe{make_float3(0, 0, 0), make_float3(0, 0, -1)};
+                const std::vector<Hit> hit = renderer.traceRays(&probe, 1);
+                std::fprintf(stderr, "traceRays probe: dist %.9g uv (%.9g, %.9g) hit %d\n", hit[0].dist, hit[0].uv[0], hit[0].uv[1], (int)(bool)hit[0]);
+            } else {
+                renderer.setScene(scene.spheres);
+            }
             Camera camera = defaultViewerCamera();
             if (have_org) camera.org = make_float3(org[0], org[1], org[2]);
             ProgressiveRenderer prog(renderer, (size_t)w, (size_t)h, (size_t)samps, camera);

@@ -78,3 +78,17 @@ def test_cpp_multi_renderer_cli(pkg, oracle, tmp_path, extra):
     assert "1 device(s)" in err and "RCCL exchange" in err
     ref, _ = oracle.render(pkg.cornell9(), 70, 51, 4, seed=5, normalise=True)
     assert out.read_bytes() == expected_ppm(oracle, ref)
+
+
+def test_main_single_triangle_scene_through_cpp_intersector(pkg, oracle, tmp_path):
+    """main()'s actual scene (SingleTriangleScene, smallpt.cpp:818-838) through the C++ Intersector seam
+    (Renderer::setMeshes = addTriangleMesh + build, traceRays) and the progressive loop: 2 frames summed."""
+    w, h = 160, 90
+    raw = tmp_path / "tri.bin"
+    err = _run([4, "--viewer", "--single-triangle", "--size", f"{w}x{h}", "--frames", 2, "--dump-raw", raw, "--out", tmp_path / "tri.ppm"])
+    assert "traceRays probe: dist 2 uv (0.25, 0.5) hit 1" in err                  # the SURVEY.md 8(c) triIntersect KAT
+    meshes, mats = pkg.single_triangle_scene()
+    cam = pkg.pinhole_camera()
+    acc = sum(oracle.render_meshes(meshes, mats, w, h, 1, seed=s, normalise=False, camera=cam)[0] for s in range(2))
+    got = np.fromfile(raw, dtype=np.float32).reshape(h, w, 3)
+    assert np.array_equal(got, acc) and got[:, :, 0].max() > 0

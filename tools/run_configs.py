@@ -26,6 +26,7 @@ def rel_l2(a, b):
 
 def run(name, scene, w, h, samps, band=None, oracle_rows=None, reps=2):
     r = pkg.Renderer(0)
+    r.set_watchdog(120.0)
     r.set_scene(scene)
     n = len(scene)
     begin, count = band if band else (0, h)
@@ -66,7 +67,8 @@ def run(name, scene, w, h, samps, band=None, oracle_rows=None, reps=2):
            "msamples_s_kernel": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
            "bounces_per_sample": round(bbar, 4), "flops_per_sample": round(fl, 1), "tflops": round(tf, 2),
            "pct_of_157.3": round(100 * tf / PEAK, 2), "pct_of_78.6": round(100 * tf / PEAK_HALF, 2),
-           "store_GBps": round(count * w * 76 / (st["finalize_ms"] * 1e-3) / 1e9, 0),
+           "store_GBps": round(count * w * (64 * (8 if samps >= 128 else 4 if samps >= 64 else 2 if samps >= 32 else 1) + 12) / (st["finalize_ms"] * 1e-3) / 1e9, 0),
+           "kernel": r.last_kernel(),
            "oracle_rows_checked": checked, "rel_l2_vs_cpu": worst, "bit_exact": exact,
            "oracle_s": round(time.perf_counter() - t0, 1)}
     print(json.dumps(row), flush=True)
@@ -89,11 +91,11 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "gpurun_out", "configs.md"), "w") as f:
-        f.write("| Config | GPUs | Msamples/s (end-to-end) | Msamples/s (kernel) | B̄ bounces/sample | flops/sample | "
+        f.write("| Config | kernel | GPUs | Msamples/s (end-to-end) | Msamples/s (kernel) | B̄ bounces/sample | flops/sample | "
                 "% of 157.3 TF | % of 78.6 TF | HBM GB/s on store | rel-L2 vs CPU (rows checked) | bit-exact |\n"
-                "|---|---|---|---|---|---|---|---|---|---|---|\n")
+                "|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for r_ in rows:
-            f.write(f"| {r_['config']} | 1 | {r_['msamples_s_end_to_end']} | {r_['msamples_s_kernel']} | {r_['bounces_per_sample']} | "
+            f.write(f"| {r_['config']} | {r_['kernel']} | 1 | {r_['msamples_s_end_to_end']} | {r_['msamples_s_kernel']} | {r_['bounces_per_sample']} | "
                     f"{r_['flops_per_sample']} | {r_['pct_of_157.3']} | {r_['pct_of_78.6']} | {r_['store_GBps']:.0f} | "
                     f"{r_['rel_l2_vs_cpu']:.1e} ({r_['oracle_rows_checked']}) | {r_['bit_exact']} |\n")
     print(open(os.path.join(ROOT, "gpurun_out", "configs.md")).read())
