@@ -67,9 +67,10 @@ def d2h_inclusive(r, samps, steps):
 
 def interactive(pkg, r, dev, frames=200):
     """Render-thread loop of the viewer (smallpt.cpp:895-942) at the reference's window size: Cornell-9 seen by the
-    pinhole Camera{vx,vy,vz,org,near=1} placed at the smallpt eye point, 1 sample per jitter cell per frame."""
+    pinhole Camera{vx,vy,vz,org,near=1} placed just inside the box's open front (the smallpt eye point lies outside the
+    front-wall sphere; cpuRender pushes its rays 140 units forward, sampleRay does not), 1 sample per jitter cell per frame."""
     w, h, samps = 1280, 720, 1
-    cam = pkg.pinhole_camera(vx=(1, 0, 0), vz=(0, 0, -1), org=(50, 52, 295.6), near=1.0)
+    cam = pkg.pinhole_camera(vx=(1, 0, 0), vz=(0, 0, -1), org=(50, 45, 168), near=1.0)
     prog = pkg.ProgressiveRenderer(r, w, h, samps, camera=cam)
     import torch
     for _ in range(10):
@@ -80,8 +81,10 @@ def interactive(pkg, r, dev, frames=200):
         prog.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / frames
+    st = r.sync()
     return {"workload": f"Cornell-9, {w}x{h}, 4 spp per frame (1 per jitter cell), pinhole camera + box-in-cell sampling, "
                         f"frame accumulated in HBM, {frames} frames", "frames_per_s": round(1.0 / dt, 1),
+            "kernel_ms": round(st["kernel_ms"], 4), "finalize_ms": round(st["finalize_ms"], 4),
             "ms_per_frame": round(dt * 1e3, 4), "value": round(w * h * 4 * samps / dt / 1e6, 1), "unit": "Msamples/s"}
 
 
@@ -181,13 +184,25 @@ def main():
         achieved = my_samples * fl / k_s / 1e12
         f_s = (sum(fms) / len(fms)) * 1e-3
         nb = 8 if samps >= 128 else (4 if samps >= 64 else (2 if samps >= 32 else 1))   # D9 sample blocks per jitter cell
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
+        # PMC-derived constants of the same command (tools/prof_round.sh -> profiles/pmc_latest.json): HBM-side bytes per launch
+        # and the VALU instruction count / lane utilisation used for the four-factor decomposition of `frac`
+        traffic, decomposition = None, None
+        prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(prof) and world == 1 and samps == SAMPS:
             try:
-                traffic = json.load(open(prof)).get("megakernel_hbm_bytes_per_launch")
+                pj = json.load(open(prof))
+                traffic = pj.get("hbm_bytes_per_launch")
+                insts, util = float(pj["valu_wave_insts_per_launch"]), float(pj["valu_lane_utilisation"])
+                simd_cycles = k_s * 2.4e9 * 1024                       # 256 CUs x 4 SIMDs at the 2.4 GHz the peak is quoted for
+                decomposition = {
+                    "no_fma": 0.5,                                      # 1 flop per lane-op (non-contracted mul/add) vs 2 for FMA
+                    "issue": round(2.0 * insts / simd_cycles, 4),       # 2 clk per wave-instruction at full rate / measured clk per instruction
+                    "lane_utilisation": round(util, 4),                 # PMC VALUUtilization (active lanes / 64)
+                    "algorithmic_share": round(my_samples * fl / (insts * 64.0 * util), 4),   # algorithmic flops per executed lane-op
+                    "valu_wave_insts_per_lane_bounce": round(insts * 64.0 / (st["bounces"] * 64.0), 3),
+                    "source": pj.get("_source", "profiles/pmc_latest.json")}
             except Exception:
-                traffic = None
+                traffic, decomposition = None, None
         out = {
             "metric": "Mega path-samples/sec at 1024x768", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,6 +216,7 @@ def main():
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                          "kernel": "spt::poolkernel" if r.last_kernel() == "pool" else "spt::megakernel", "kernel_ms": round(k_s * 1e3, 3),
                          "flops_per_sample": round(fl, 1), "bounces_per_sample": round(bbar, 4),
+                         "decomposition": decomposition,
                          "note": "FP32 VALU-bound (no MFMA-shaped work, HBM traffic ~12 B/pixel/launch); algorithmic "
                                  "flops per SURVEY.md 8(d); arithmetic is non-contracted IEEE mul/add (1 flop/instr) "
                                  "for bit-parity with the reference's host arithmetic, so frac <= 0.5 by construction",

@@ -123,6 +123,14 @@ def load_library():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 under torch/lib).  If this library
+    # pulled in the system runtime first, a later `import torch` in the same process would initialise a second HSA
+    # runtime and report "No HIP GPUs are available"; loading torch's runtime first makes both share one.  Plumbing only
+    # (device tensors / streams / torch.distributed); nothing of the render path runs through torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in {**SYMBOLS, **INTERNAL_SYMBOLS}.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -479,42 +479,54 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
 }
 
 // D9: cell = ((B0 + B1) + B2) + ... over its nb block sums, pixel = ((c0 + c1) + c2) + c3, optional * (1/spp)
-// (smallpt.cpp:358-361).  One lane per pixel: 4 * nb contiguous float4 block sums in, 12 B out.  The packed float3 rows
-// are written with coalesced 16-byte stores: the workgroup's 256 pixels (3 KB) are transposed through LDS and stored as
-// 192 float4 (ALIGNED16 build; the scalar build serves output pointers that are not 16-byte aligned).  HBM-bound.
+// (smallpt.cpp:358-361).  A workgroup finishes 64 pixels = 256 jitter cells: their 256 * nb block sums (contiguous in
+// HBM) are loaded with fully coalesced 16-byte loads into LDS, one padded row of nb + 1 float4 per cell (the odd row
+// pitch makes the per-cell ds_read_b128 conflict-free); then one lane per cell adds its row in block order, the four
+// cell sums of a pixel meet in the first lane of the quad, and the 64 packed float3 (768 B) are transposed through LDS
+// and written as 48 coalesced 16-byte stores (ALIGNED16 build; the scalar build serves output pointers that are not
+// 16-byte aligned).  HBM-bound: 64 * nb + 12 bytes per pixel.
 template <bool ALIGNED16>
 __global__ __launch_bounds__(kBlock) void finalize(const float4* __restrict__ cells, float* __restrict__ out,
-                                                   uint32_t npix, float scale, int normalise, uint32_t nb)
+                                                   uint32_t npix, float scale, int normalise, uint32_t nb, uint32_t nb_log2)
 {
-    __shared__ float4 s_px[(kBlock * 3) / 4];
-    const uint32_t base = blockIdx.x * kBlock;
-    const uint32_t p = base + threadIdx.x;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (p < npix) {
-        const float4* c = cells + (size_t)p * 4u * nb;
-        float cx[4], cy[4], cz[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 a = c[g * nb];
-            for (uint32_t k = 1; k < nb; ++k) {
-                const float4 v = c[g * nb + k];
-                a.x += v.x; a.y += v.y; a.z += v.z;
-            }
-            cx[g] = a.x; cy[g] = a.y; cz[g] = a.z;
-        }
-        x = ((cx[0] + cx[1]) + cx[2]) + cx[3];
-        y = ((cy[0] + cy[1]) + cy[2]) + cy[3];
-        z = ((cz[0] + cz[1]) + cz[2]) + cz[3];
-        if (normalise) { x *= scale; y *= scale; z *= scale; }
+    constexpr uint32_t kPix = kBlock / 4;                       // pixels per workgroup
+    extern __shared__ float4 s_rows[];                          // 256 x (nb + 1) float4, then the 768-byte output tile
+    float4* const s_px = s_rows + kBlock * (nb + 1u);
+    const uint32_t base = blockIdx.x * kPix;
+    const size_t cell0 = (size_t)blockIdx.x * kBlock;           // first cell of the workgroup
+    const size_t ncell = (size_t)npix * 4u;
+    for (uint32_t j = 0; j < nb; ++j) {
+        const uint32_t e = j * kBlock + threadIdx.x;            // element of the workgroup's contiguous 256 * nb float4
+        const uint32_t c = e >> nb_log2, k = e & (nb - 1u);
+        if (cell0 + c < ncell) s_rows[c * (nb + 1u) + k] = cells[cell0 * nb + e];
     }
-    const bool full = base + kBlock <= npix;       // workgroup-uniform
+    __syncthreads();
+    const uint32_t p = base + (threadIdx.x >> 2);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < npix) {
+        const float4* row = s_rows + threadIdx.x * (nb + 1u);
+        a = row[0];
+        for (uint32_t k = 1; k < nb; ++k) {
+            const float4 v = row[k];
+            a.x += v.x; a.y += v.y; a.z += v.z;
+        }
+    }
+    // lanes 4q .. 4q+3 hold c0 .. c3 of one pixel: ((c0 + c1) + c2) + c3 in lane 4q
+    const float x1 = __shfl_down(a.x, 1), y1 = __shfl_down(a.y, 1), z1 = __shfl_down(a.z, 1);
+    const float x2 = __shfl_down(a.x, 2), y2 = __shfl_down(a.y, 2), z2 = __shfl_down(a.z, 2);
+    const float x3 = __shfl_down(a.x, 3), y3 = __shfl_down(a.y, 3), z3 = __shfl_down(a.z, 3);
+    float x = ((a.x + x1) + x2) + x3, y = ((a.y + y1) + y2) + y3, z = ((a.z + z1) + z2) + z3;
+    if (normalise) { x *= scale; y *= scale; z *= scale; }
+    const bool lead = (threadIdx.x & 3u) == 0u;
+    const uint32_t q = threadIdx.x >> 2;                        // pixel within the workgroup
+    const bool full = base + kPix <= npix;                      // workgroup-uniform
     if (ALIGNED16 && full) {
         float* s = reinterpret_cast<float*>(s_px);
-        s[3 * threadIdx.x + 0] = x; s[3 * threadIdx.x + 1] = y; s[3 * threadIdx.x + 2] = z;
+        if (lead) { s[3 * q + 0] = x; s[3 * q + 1] = y; s[3 * q + 2] = z; }
         __syncthreads();
-        if (threadIdx.x < (kBlock * 3) / 4)
+        if (threadIdx.x < (kPix * 3) / 4)
             reinterpret_cast<float4*>(out + (size_t)base * 3)[threadIdx.x] = s_px[threadIdx.x];
-    } else if (p < npix) {
+    } else if (lead && p < npix) {
         out[3 * (size_t)p + 0] = x; out[3 * (size_t)p + 1] = y; out[3 * (size_t)p + 2] = z;
     }
 }
@@ -623,11 +635,15 @@ extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int m
 
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream)
 {
-    const uint32_t blocks = (npix + spt::kBlock - 1) / spt::kBlock;
-    if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)     // 256 pixels * 12 B = 3 KB per workgroup keeps every block base aligned
-        hipLaunchKernelGGL(spt::finalize<true>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise, nb);
+    const uint32_t per_block = spt::kBlock / 4;                 // 64 pixels * 12 B = 768 B per workgroup keeps every block base 16-byte aligned
+    const uint32_t blocks = (npix + per_block - 1) / per_block;
+    uint32_t nb_log2 = 0;
+    while ((1u << nb_log2) < nb) ++nb_log2;
+    const size_t lds = ((size_t)spt::kBlock * (nb + 1u) + (per_block * 3) / 4) * sizeof(float4);
+    if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)
+        hipLaunchKernelGGL(spt::finalize<true>, dim3(blocks), dim3(spt::kBlock), lds, stream, cells, out, npix, scale, normalise, nb, nb_log2);
     else
-        hipLaunchKernelGGL(spt::finalize<false>, dim3(blocks), dim3(spt::kBlock), 0, stream, cells, out, npix, scale, normalise, nb);
+        hipLaunchKernelGGL(spt::finalize<false>, dim3(blocks), dim3(spt::kBlock), lds, stream, cells, out, npix, scale, normalise, nb, nb_log2);
     return hipGetLastError();
 }
 

@@ -372,21 +372,28 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             // index among equal nearest distances (:61 strict <).
             uint32_t nk[3 * NG + 1];
             nk[0] = kInfKeyP;
-#define SPT_PSPH(i)                                                                         \
-            if ((i) < 3 * NG) {                                                             \
-                const float4 g = s_geom[(i)];                                               \
-                const f3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);                          /* :132 */ \
-                const float bb = dot(op, d);                                                /* :133 */ \
-                const float det = bb * bb - dot(op, op) + g.w;                              /* :133 (g.w = r*r) */ \
-                const float sd = sqrt_fix_int(det);                                         /* :134 */ \
-                const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;                  /* :135 */ \
-                const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;                  \
-                nk[(i) + 1] = umin3(nk[(i)], key1, key2);                                   \
+            // the wave-uniform (broadcast) LDS reads of up to nine spheres are issued together ahead of their arithmetic:
+            // one LDS round trip per chunk instead of one per sphere (it is the latency of a wave with few live paths --
+            // the end of a launch -- that this shortens)
+#pragma unroll
+            for (int base = 0; base < 3 * NG; base += 9) {
+                float4 g[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    if (base + j < 3 * NG) g[j] = s_geom[base + j];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    if (base + j < 3 * NG) {
+                        const f3 op = mk(g[j].x - o.x, g[j].y - o.y, g[j].z - o.z);         // :132
+                        const float bb = dot(op, d);                                        // :133
+                        const float det = bb * bb - dot(op, op) + g[j].w;                   // :133 (g.w = r*r)
+                        const float sd = sqrt_fix_int(det);                                 // :134
+                        const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;          // :135
+                        const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;
+                        nk[base + j + 1] = umin3(nk[base + j], key1, key2);
+                    }
+                }
             }
-            SPT_PSPH(0) SPT_PSPH(1) SPT_PSPH(2) SPT_PSPH(3) SPT_PSPH(4) SPT_PSPH(5) SPT_PSPH(6) SPT_PSPH(7)
-            SPT_PSPH(8) SPT_PSPH(9) SPT_PSPH(10) SPT_PSPH(11) SPT_PSPH(12) SPT_PSPH(13) SPT_PSPH(14) SPT_PSPH(15)
-            SPT_PSPH(16) SPT_PSPH(17) SPT_PSPH(18) SPT_PSPH(19) SPT_PSPH(20) SPT_PSPH(21) SPT_PSPH(22) SPT_PSPH(23)
-#undef SPT_PSPH
             const uint32_t near_key = nk[3 * NG];
             // ---- class-independent part of shadePaths (smallpt.cpp:168-198) ----
             if (near_key != kInfKeyP) {                                                     // else :168 miss (D13)
