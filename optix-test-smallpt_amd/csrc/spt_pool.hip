@@ -36,6 +36,9 @@ constexpr int kPoolBlock = 256;
 constexpr uint32_t kNoTask = 0xFFFFFFFFu;
 constexpr int kStackWords = 12;                                  // one pending child = 3 float4: {o, depth|branch<<16} {d, k0} {w, k1}
 constexpr int kMaxUnroll = 24;                                   // spheres handled by the unrolled closest-hit code
+#ifndef SPT_POOL_NARROW
+#define SPT_POOL_NARROW 1                                        // lane-parallel closest hit for batches of <= 4 rays
+#endif
 #ifndef SPT_POOL_TASK_LDS
 #define SPT_POOL_TASK_LDS 1                                      // {task id, next sample} of a slot in LDS (else in global memory)
 #endif
@@ -48,6 +51,7 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     uint32_t it_total = 0;
     bool timed_out = false;
+    unsigned long long t_dry = 0;                                // when this wave found the task queue empty
 
     for (;;) {
         // ---- choose the class of this batch: a full batch of the rarest class first, else the longest list ----
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                         uint32_t nb = 0;
                         if ((int)lane == leader) nb = atomicAdd(K.queue, 64u);
                         base_new = uni(__shfl(nb, leader));
-                        if (base_new >= K.ntasks) queue_empty = true;
+                        if (base_new >= K.ntasks) { queue_empty = true; t_dry = __builtin_amdgcn_s_memtime(); }
                     } else {
                         base_new = K.ntasks;                     // nothing left: ids >= ntasks mean "no task"
                     }
@@ -366,15 +371,48 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         nbounce += (unsigned long long)__popcll(__ballot(has_ray));
         uint32_t next = C_GEN;                                   // slots without a continuing path go back to GEN
         const bool queued = valid && !retired;
-        if (has_ray) {
+        uint32_t near_key = kInfKeyP, inst = 0;
+        if (SPT_POOL_NARROW && 3 * NG <= 16 && b <= 4u) {
+            // ---- narrow closest hit: a batch of <= 4 rays (the end of a launch: its duration is set by the last, longest
+            // paths) spreads the sphere tests over the wave -- lane 16 r + i tests sphere i for ray r -- instead of
+            // running all of them in <= 4 lanes: ~60 instead of ~340 instructions on the critical path.  Same keys, same
+            // winner: unsigned minimum over the row, lowest sphere index among equal keys.  All 64 lanes take part. ----
+            const uint32_t r = lane >> 4, si = lane & 15u;
+            const f3 ro = mk(__shfl(o.x, r), __shfl(o.y, r), __shfl(o.z, r));
+            const f3 rd = mk(__shfl(d.x, r), __shfl(d.y, r), __shfl(d.z, r));
+            uint32_t key = 0xFFFFFFFFu;
+            if (si < 3u * NG) {
+                const float4 g = s_geom[si];
+                const f3 op = mk(g.x - ro.x, g.y - ro.y, g.z - ro.z);                       // :132
+                const float bb = dot(op, rd);                                               // :133
+                const float det = bb * bb - dot(op, op) + g.w;                              // :133
+                const float sd = sqrt_fix_int(det);                                         // :134
+                const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;                  // :135
+                const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;
+                key = key1 < key2 ? key1 : key2;
+            }
+            // minimum over each row of 16 lanes by DPP row rotations (no LDS round trips on the critical path)
+            uint32_t m = key;
+            m = umin2(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x121, 0xF, 0xF, false));   // row_ror:1
+            m = umin2(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x122, 0xF, 0xF, false));   // row_ror:2
+            m = umin2(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x124, 0xF, 0xF, false));   // row_ror:4
+            m = umin2(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x128, 0xF, 0xF, false));   // row_ror:8
+            const unsigned long long eq = __ballot(key == m);                               // row r: bits 16 r .. 16 r + 15
+            const uint32_t row = (uint32_t)(eq >> ((lane & 3u) * 16u)) & 0xFFFFu;           // lane r < 4 looks at its ray's row
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_readlane((int)m, 16), m2 = (uint32_t)__builtin_amdgcn_readlane((int)m, 32),
+                           m3 = (uint32_t)__builtin_amdgcn_readlane((int)m, 48);
+            const uint32_t mrow = lane == 1u ? m1 : (lane == 2u ? m2 : (lane == 3u ? m3 : m));   // lane 0 sits in row 0
+            if (has_ray) {                                                                  // ray r lives in lane r
+                near_key = mrow < kInfKeyP ? mrow : kInfKeyP;
+                inst = (uint32_t)__ffs((int)row) - 1u;                                      // :61 strict <: lowest index wins ties
+            }
+        } else if (has_ray) {
             // nk[i + 1] = min(nk[i], key1, key2) of sphere i: one v_min3_u32 per sphere; the index of the winner is
-            // recovered afterwards (hit lanes only) as the last i at which the running minimum changed = the lowest
-            // index among equal nearest distances (:61 strict <).
+            // recovered afterwards as the last i at which the running minimum changed = the lowest index among equal
+            // nearest distances (:61 strict <).
             uint32_t nk[3 * NG + 1];
             nk[0] = kInfKeyP;
-            // the wave-uniform (broadcast) LDS reads of up to nine spheres are issued together ahead of their arithmetic:
-            // one LDS round trip per chunk instead of one per sphere (it is the latency of a wave with few live paths --
-            // the end of a launch -- that this shortens)
+            // the wave-uniform (broadcast) LDS reads of up to nine spheres are issued together ahead of their arithmetic
 #pragma unroll
             for (int base = 0; base < 3 * NG; base += 9) {
                 float4 g[9];
@@ -394,14 +432,15 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                     }
                 }
             }
-            const uint32_t near_key = nk[3 * NG];
+            near_key = nk[3 * NG];
+#pragma unroll
+            for (int i = 1; i < 3 * NG; ++i)
+                if (nk[i + 1] != nk[i]) inst = (uint32_t)i;
+        }
+        if (has_ray) {
             // ---- class-independent part of shadePaths (smallpt.cpp:168-198) ----
             if (near_key != kInfKeyP) {                                                     // else :168 miss (D13)
                 const float t = __uint_as_float(near_key + kEpsBias);
-                uint32_t inst = 0;
-#pragma unroll
-                for (int i = 1; i < 3 * NG; ++i)
-                    if (nk[i + 1] != nk[i]) inst = (uint32_t)i;
                 const float4 me = s_mat[3 * inst + 0];                                      // emission.xyz, refl | emissive << 2
                 const float4 mc = s_mat[3 * inst + 1];                                      // color.xyz, pmax
                 const uint32_t rb = __float_as_uint(me.w);
@@ -466,6 +505,12 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         if (timed_out) atomicAdd(&K.counters[8], 1ull);
         atomicAdd(&K.counters[9], (unsigned long long)itTail); atomicAdd(&K.counters[10], lnTail);
         atomicAdd(&K.counters[11], (unsigned long long)itFull);
+        // launch timeline in s_memtime ticks, wave-local differences only (the counter is not synchronised across XCDs):
+        // longest wave, longest and summed time a wave kept running after it found the task queue empty
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicMax(&K.counters[12], t_end - t_start);
+        if (t_dry) { atomicMax(&K.counters[13], t_end - t_dry); atomicAdd(&K.counters[14], t_end - t_dry); }
+        atomicAdd(&K.counters[15], t_end - t_start);
     }
 }
 

@@ -157,3 +157,25 @@ def test_viewer_request_messages_through_the_json_reader():
     assert run('{"action": "update_camera"}').returncode == 1            # org missing
     assert run('{"action": "update_camera", "org": [1, 2]}').returncode == 1
     assert run('{"action": "update_camera", "org": [1, 2, 3]').returncode == 1      # malformed JSON
+
+
+def test_cmake_build_of_libraries_and_cli(tmp_path):
+    """north_star: "Host side stays C++ (CMake)".  Configures and builds host/CMakeLists.txt out of tree (both libraries,
+    the RCCL link, the CLI) and runs the host-only path of the resulting program."""
+    import shutil
+    import subprocess
+    if shutil.which("cmake") is None or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("cmake or the ROCm clang not available")
+    src = os.path.join(ROOT, "optix-test-smallpt_amd", "host")
+    b = str(tmp_path / "build")
+    r = subprocess.run(["cmake", "-S", src, "-B", b, "-DCMAKE_HIP_COMPILER=/opt/rocm/lib/llvm/bin/clang++",
+                        "-DCMAKE_HIP_ARCHITECTURES=gfx950"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", b, "-j", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for f in ("libsmallpt_mi355x.so", "libsmallpt_mi355x_multi.so", "smallpt_mi355x"):
+        assert os.path.exists(os.path.join(b, f)), f
+    ldd = subprocess.run(["ldd", os.path.join(b, "libsmallpt_mi355x_multi.so")], capture_output=True, text=True).stdout
+    assert "librccl" in ldd and "libsmallpt_mi355x.so" in ldd
+    raw = subprocess.check_output([os.path.join(b, "smallpt_mi355x"), "--parse-only"])
+    assert len(raw) == 9 * 48

@@ -19,7 +19,12 @@ def pool_report(r, st):
     d = r.diag()
     it, ln = d[0:3], d[3:6]
     tot_it, tot_ln = sum(it), sum(ln)
-    return (f"batches GEN/DIFF/REFR {it} lanes/batch "
+    tl = ""
+    if d[10]:
+        nw = st["grid_blocks"] * 4
+        tl = (f" | timeline (wave-local): longest wave {d[10] / 2.4e6:.2f} ms (at 2.4 GHz ticks), mean wave {d[13] / nw / 2.4e6:.2f} ms, "
+              f"after its queue-dry point a wave runs {d[12] / nw / 2.4e6:.2f} ms on average, {d[11] / 2.4e6:.2f} ms at most")
+    return tl + " " + (f"batches GEN/DIFF/REFR {it} lanes/batch "
             f"{[round(l / max(i, 1), 1) for l, i in zip(ln, it)]} overall fill {tot_ln / max(tot_it, 1) / 64:.3f} "
             f"full batches {d[9] / max(tot_it, 1):.3f} tail batches {d[7] / max(tot_it, 1):.3f} tail fill {d[8] / max(d[7], 1) / 64:.3f} "
             f"pre-tail fill {(tot_ln - d[8]) / max(tot_it - d[7], 1) / 64:.3f}")
