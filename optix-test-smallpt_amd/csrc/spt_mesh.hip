@@ -33,7 +33,8 @@ __device__ __forceinline__ float rcp_signed(float x)
     return __uint_as_float(__float_as_uint(r) | (__float_as_uint(x) & 0x80000000u));
 }
 
-// triIntersect against one staged triangle record; returns t (1e20 when the barycentrics reject it) and u, v
+// triIntersect against one staged triangle record; returns t (1e20 when the barycentrics reject it) and u, v.
+// Branch-free: the four rejection tests of scene.cpp:67 are evaluated together (same truth value as the short-circuit form).
 __device__ __forceinline__ float tri_test(const float4 r0, const float4 r1, const float4 r2, f3 ro, f3 rd, float& u, float& v)
 {
     const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z), n = mk(r0.w, r1.w, r2.w);
@@ -42,9 +43,9 @@ __device__ __forceinline__ float tri_test(const float4 r0, const float4 r1, cons
     const float d = rcp_signed(dot(rd, n));                                      // :62
     u = d * dot(neg(q), e2);                                                     // :63
     v = d * dot(q, e1);                                                          // :64
-    float t = d * dot(neg(n), rov0);                                             // :65
-    if (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) t = 1e20f;           // :67
-    return t;
+    const float t = d * dot(neg(n), rov0);                                       // :65
+    const bool rej = (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | ((u + v) > 1.0f);    // :67
+    return rej ? 1e20f : t;
 }
 
 // Closest hit over every triangle (see the header).  All threads of the workgroup must call this together (the tiles are
@@ -53,20 +54,33 @@ __device__ __forceinline__ uint32_t closest_triangle(const float4* __restrict__ 
                                                      bool active, f3 ro, f3 rd, float& t_out)
 {
     uint32_t near_key = kMeshInfKey, near_tri = 0xFFFFFFFFu;
+    // "t > 0 && t < nearest" (scene.cpp:105, smallpt.cpp:449) as one unsigned compare on key = bits(t) - 1: +0 wraps to
+    // the top, negative and NaN keys lie above the key of 1e20; ascending order + strict '<' = lowest index wins ties
+    auto consider = [&](const float4 r0, const float4 r1, const float4 r2, uint32_t index) {
+        float u, v;
+        const float t = tri_test(r0, r1, r2, ro, rd, u, v);
+        const uint32_t key = __float_as_uint(t) - 1u;
+        const bool better = key < near_key;
+        near_key = better ? key : near_key;
+        near_tri = better ? index : near_tri;
+    };
     for (uint32_t base = 0; base < ntris; base += kTile) {
         const uint32_t cnt = ntris - base < (uint32_t)kTile ? ntris - base : (uint32_t)kTile;
         __syncthreads();                                       // the previous tile is no longer read
         for (uint32_t i = threadIdx.x; i < 3u * cnt; i += blockDim.x) s_tile[i] = tris[3u * (size_t)base + i];
         __syncthreads();
         if (active) {
-            for (uint32_t k = 0; k < cnt; ++k) {
-                float u, v;
-                const float t = tri_test(s_tile[3 * k], s_tile[3 * k + 1], s_tile[3 * k + 2], ro, rd, u, v);
-                // "t > 0 && t < nearest" (scene.cpp:105, smallpt.cpp:449) as one unsigned compare on key = bits(t) - 1:
-                // +0 wraps to the top, negative and NaN keys lie above the key of 1e20
-                const uint32_t key = __float_as_uint(t) - 1u;
-                if (key < near_key) { near_key = key; near_tri = base + k; }
+            uint32_t k = 0;
+            for (; k + 4 <= cnt; k += 4) {                     // four records (12 broadcast reads) in flight per LDS round trip
+                const float4* r = s_tile + 3 * k;
+                const float4 a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[3], b1 = r[4], b2 = r[5];
+                const float4 c0 = r[6], c1 = r[7], c2 = r[8], d0 = r[9], d1 = r[10], d2 = r[11];
+                consider(a0, a1, a2, base + k);
+                consider(b0, b1, b2, base + k + 1);
+                consider(c0, c1, c2, base + k + 2);
+                consider(d0, d1, d2, base + k + 3);
             }
+            for (; k < cnt; ++k) consider(s_tile[3 * k], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k);
         }
     }
     t_out = __uint_as_float(near_key + 1u);
