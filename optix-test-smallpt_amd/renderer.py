@@ -239,17 +239,35 @@ class ProgressiveRenderer:
     (Renderer::render convention), adds it to the accumulation tensor (:935) and returns the display weight
     1/(frames*spp) of :957.  ``update_camera`` mirrors the "update_camera" request (:911-916): new camera,
     the next frame is still rendered with the RUNNING frame counter as its seed (:922), replaces the buffer
-    (:931-935), and only then is the counter reset to 1 (:938-939)."""
+    (:931-935), and only then is the counter reset to 1 (:938-939).
 
-    def __init__(self, renderer, w, h, samps_per_cell, camera=None):
+    ``pipeline=2`` keeps two frames in flight on two contexts/streams of the same device: frame k+1 starts while the
+    last, longest paths of frame k are still finishing (the end of a 4-spp frame is a handful of mirror<->glass chains,
+    DESIGN.md section 5), the accumulation kernels stay in frame order (stream events), so ``accum`` is bit-identical
+    to the serial loop; ``step()`` then returns without waiting and ``flush()`` waits for everything in flight."""
+
+    def __init__(self, renderer, w, h, samps_per_cell, camera=None, pipeline=1):
         import torch
         self.r, self.w, self.h, self.samps = renderer, w, h, samps_per_cell
         self.camera = camera if camera is not None else pinhole_camera()
         dev = torch.device("cuda", renderer.device_id)
         self.accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
-        self.frame = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
         self.frames = 0          # sampleCount, smallpt.cpp:893
         self._clear = True       # the zero-initialised accumBuffer (:882): replacing it == adding to zeros
+        self.pipeline = max(1, int(pipeline))
+        self._lanes = []
+        for i in range(self.pipeline):
+            rr = renderer if i == 0 else Renderer(renderer.device_id)
+            if i and renderer._scene is not None:
+                rr.set_scene(renderer._scene)
+            self._lanes.append({"r": rr, "frame": torch.empty((h, w, 3), dtype=torch.float32, device=dev),
+                                # alternate stream priorities: HIP maps equal-priority streams of a process onto a shared hardware queue,
+                                # which would serialise the two frames
+                                "stream": torch.cuda.current_stream(dev) if self.pipeline == 1 else torch.cuda.Stream(dev, priority=-(i % 2)),
+                                "done": None})
+        self.frame = self._lanes[0]["frame"]
+        self._issued = 0
+        self._last_acc = None    # event after the most recent accumulation kernel
 
     def update_camera(self, camera):
         self.camera = camera
@@ -257,17 +275,38 @@ class ProgressiveRenderer:
 
     def step(self):
         import torch
-        stream = torch.cuda.current_stream().cuda_stream
+        lane = self._lanes[self._issued % self.pipeline]
+        self._issued += 1
+        r, stream = lane["r"], lane["stream"]
         seed = self.frames       # :922 renders with the running sampleCount, also on the clearing frame
-        self.r.render_rows_device(self.frame, self.w, self.h, 0, self.h, self.samps, seed=seed, normalise=False,
-                                  camera=self.camera, stream=stream)
-        self.r._check(self.r._lib.spt_accumulate_device(self.r._h, C.c_void_p(self.accum.data_ptr()),
-                                                        C.c_void_p(self.frame.data_ptr()), self.accum.numel(),
-                                                        1 if self._clear else 0, C.c_void_p(stream)))
+        if self.pipeline > 1 and lane["done"] is not None:
+            stream.wait_event(lane["done"])               # the lane's frame buffer was read by its last accumulation
+        r.render_rows_device(lane["frame"], self.w, self.h, 0, self.h, self.samps, seed=seed, normalise=False,
+                             camera=self.camera, stream=stream.cuda_stream)
+        if self.pipeline > 1 and self._last_acc is not None:
+            stream.wait_event(self._last_acc)             # accumulations stay in frame order
+        r._check(r._lib.spt_accumulate_device(r._h, C.c_void_p(self.accum.data_ptr()), C.c_void_p(lane["frame"].data_ptr()),
+                                               self.accum.numel(), 1 if self._clear else 0, C.c_void_p(stream.cuda_stream)))
+        if self.pipeline > 1:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            lane["done"] = self._last_acc = ev
         self.frames = 1 if self._clear else self.frames + 1
         self._clear = False
-        self.r.sync()
+        if self.pipeline == 1:
+            r.sync()
         return 1.0 / (self.frames * 4 * self.samps)
+
+    def flush(self):
+        """Waits for every frame in flight (needed before reading ``accum`` when pipeline > 1)."""
+        for lane in self._lanes:
+            lane["stream"].synchronize()
+            lane["r"].sync()
+
+    def close(self):
+        self.flush()
+        for lane in self._lanes[1:]:
+            lane["r"].close()
 
 
 def to_int(x):
