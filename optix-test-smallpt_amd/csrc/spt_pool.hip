@@ -3,9 +3,10 @@
 // Same algorithm and arithmetic as spt_kernel.hip (the per-bounce host loop { Intersector::traceRays ->
 // shadePaths -> compact } of smallpt.cpp:349-356 / :779-807 collapsed into one launch), different scheduling:
 //
-//   * every WAVE owns a private pool of P path slots in LDS (P = 2 x 64 by default).  A slot is one task
-//     (= one jitter cell of one pixel, smallpt.cpp:299-309) with at most one path in flight, so emission
-//     events of a cell are accumulated in exactly the order of D9 (sample-ascending, DFS pre-order).
+//   * every WAVE owns a private pool of P path slots in LDS (P = 144 by default).  A slot is one task
+//     (= one D9 block of consecutive samples of one jitter cell of one pixel, smallpt.cpp:299-309) with at most
+//     one path in flight, so emission events of a block are accumulated in exactly the order of D9
+//     (sample-ascending, DFS pre-order).
 //   * slots wait in one of three wave-private LIFO lists by the NEXT thing their path needs:
 //       GEN   start the next camera sample / pop a pending transmitted child / fetch a new task
 //       DIFF  shade a DIFF or SPEC hit   (smallpt.cpp:208-223)
@@ -14,15 +15,17 @@
 //     active, then -- in the same lanes -- the closest-hit query (smallpt.cpp:54-70) and the class-independent
 //     part of shadePaths (emission, Russian roulette, weight update, :170-198), and pushes each slot onto
 //     the list of its next class.  The megakernel of spt_kernel.hip runs DIFF shading at ~69 % and glass
-//     shading at ~18 % lane utilisation because a lane owns its path; here a batch is >= 93 % full
-//     (P = 128: three lists hold 128 entries, see tools/pool_sim.py) at the price of one LDS round trip of
-//     the 48-byte path state per bounce.  No cross-wave communication, no barriers after scene staging.
-//   * LDS per slot (62 bytes): path state between the phases {hit point, rbase} {direction, depth|branch|inst|refl|
-//     stack count} {weight, k1} as three float4, the block sum of the task as three floats, one byte in the GEN list
-//     and one in the array shared by the DIFF list (growing up) and the REFR list (growing down).  {task id, next
-//     sample} of a slot (only needed when a new path starts) and the <= 3 pending transmitted children of the glass
-//     split (smallpt.cpp:252) live in global memory.  128 slots per wave = 31.6 KB per 256-thread workgroup: five
-//     workgroups (20 waves) per CU.
+//     shading at ~18 % lane utilisation because a lane owns its path; here a batch is ~96 % full
+//     (three lists hold 144 entries; tools/pool_sim.py models the policy, the kernel counts its batches) at
+//     the price of one LDS round trip of the 48-byte path state per bounce.  No cross-wave communication, no
+//     barriers after scene staging.
+//   * LDS per slot (70 bytes): path state between the phases {hit point, rbase} {direction, depth|branch|inst|refl|
+//     stack count} {weight, k1} as three float4, the block sum of the task as three floats, {task id, next sample},
+//     one byte in the GEN list and one in the array shared by the DIFF list (growing up) and the REFR list (growing
+//     down).  144 slots per wave = 40 KB per 256-thread workgroup: four workgroups (16 waves) per CU.  The <= 3
+//     pending transmitted children of the glass split (smallpt.cpp:252) are 48-byte records in global memory.
+//   * A batch of <= 4 rays (the end of a launch, whose duration the last mirror <-> glass chains set) runs the closest hit
+//     lane-parallel: lane 16 r + i tests sphere i for ray r, the row minimum comes from DPP rotations.
 //   * RNG (D7), summation order (D9), sin/cos (D17), depth cap (D18), zero-weight cut (D19) and every
 //     arithmetic expression are those of spt_kernel.hip / the oracle: results are bit-identical.
 #include "spt_device.h"
