@@ -546,6 +546,16 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
 
+    {
+        const size_t need_stack = spt_k_stack_floats((uint32_t)blocks, threads);
+        if (need_stack > c->stack_cap) {
+            if (c->d_stack) (void)hipFree(c->d_stack);
+            c->d_stack = nullptr; c->stack_cap = 0;
+            SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_stack), need_stack * sizeof(float)));
+            c->stack_cap = need_stack;
+        }
+        P.stack = c->d_stack;
+    }
     SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
     SPT_HIP(c, hipEventRecord(c->ev_start, st));
     SPT_HIP(c, spt_k_launch(&P, (uint32_t)blocks, mat_lds, (c->needs_guard || !(cam_big <= 1e15f)) ? 1 : 0, (c->variant & 0x100u) ? 1 : 0, (c->n > 24u) ? 1 : 0, big_block, st));

@@ -31,8 +31,9 @@ struct KParams {
     uint32_t* queue;         // task queue head (zeroed before launch)
     unsigned long long* counters;  // [0] bounces, [1] depth-cap kills, [2..16] DIAG phase times / lane counts
                                    // pool kernel: [2..4] batches per class (GEN, DIFF, REFR), [5..7] lanes per class, [8] watchdog hits
+    float* stack;                  // pending transmitted children of the glass split: 64-byte records in global memory
+                                   // (pool kernel: waves x slots x 3; megakernel / mesh kernel: threads x 3)
     // pool kernel (spt_pool.hip) only
-    float* stack;                  // pending transmitted children: waves x 3 entries x 12 words x pool slots
     uint2* slot_state;             // waves x pool slots x {task id, next sample}
     unsigned long long watchdog_ticks;  // s_memtime ticks after which a wave gives up (0 = never)
 };
@@ -54,6 +55,7 @@ extern "C" size_t spt_mesh_stack_floats(uint32_t blocks);
 extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_rays, uint64_t nrays, float* d_hits, hipStream_t stream);
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block);
+extern "C" size_t spt_k_stack_floats(uint32_t blocks, int block_threads);
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream);
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream);
 extern "C" int spt_k_block_threads(void);

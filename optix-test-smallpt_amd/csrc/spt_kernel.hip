@@ -3,8 +3,9 @@
 // Replaces the reference's per-bounce host loop { Intersector::traceRays -> shadePaths -> compact }
 // (smallpt.cpp:349-356 / :779-807) by one launch in which every lane owns a path from camera ray to
 // termination:
-//   * work unit ("task") = one jitter cell of one pixel (pixel*4 + sy*2+sx, smallpt.cpp:299-309);
-//     a lane runs the task's `samps` samples in order and writes ONE 16-byte cell sum.  Lanes take
+//   * work unit ("task") = one D9 block of consecutive samples of one jitter cell of one pixel
+//     (((pixel*4 + sy*2+sx) << nb_log2) | block, smallpt.cpp:299-309); a lane runs the block's samples in order
+//     and writes ONE 16-byte block sum.  Lanes take
 //     tasks from their wave's private chunk of 64 task ids; a wave touches the global queue word once
 //     per chunk, so there is neither a per-tile tail nor contention on the queue.
 //   * the recursive radiance() / the wavefront path buffers become an iterative loop with path
@@ -15,8 +16,9 @@
 //   * RNG is counter-based (D7), so the image does not depend on grid size, scheduling or GPU count.
 //   * every float operation is one IEEE binary32 operation (-ffp-contract=off); the short sqrt /
 //     reciprocal sequences of spt_device.h are proven correctly rounded (tools/verify_exact_math.c).
-// A second small kernel folds the four cell sums of a pixel in fixed order, normalises and writes the
-// packed float3 rows with coalesced 16-byte stores (D9).
+// A second small kernel folds the block sums of a pixel's four cells in fixed order, normalises and writes the
+// packed float3 rows with coalesced 16-byte stores (D9).  This kernel serves tables of more than 24 spheres, scenes
+// that need the range-guarded sqrt and colours outside [0,1]; everything else runs spt_pool.hip.
 #include "spt_device.h"
 #include "spt_kernel.h"
 
@@ -27,9 +29,9 @@ constexpr float kInf = 1e20f;   // maths.h:16
 constexpr uint32_t kEpsKeyBias = 0x38D1B717u + 1u;            // bits(1e-4f) + 1
 constexpr uint32_t kInfKey = 0x60AD78ECu - kEpsKeyBias;       // key of 1e20f (maths.h:16)
 
-// Per-thread LDS stack of pending transmitted children of the glass split (smallpt.cpp:252), <= 3 per
-// lane, laid out [entry][field][thread] so that every access is conflict-free.
-constexpr int kStackFields = 10;   // o.xyz d.xyz w.xyz (depth | branch << 16)
+// Per-thread stack of pending transmitted children of the glass split (smallpt.cpp:252), <= 3 per lane, in global
+// memory: one 64-byte line per record {o, depth | branch << 16} {d, -} {w, -} {pad} (pushes and pops are rare; keeping
+// the stack out of LDS lets a CU hold more workgroups, which is what the large-table scenes need).
 constexpr int kStackEntries = 3;
 constexpr int kChunk = 64;         // task ids fetched from the global queue per atomic
 
@@ -96,7 +98,6 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
     extern __shared__ float4 lds[];
     float4* s_geom = lds;                                  // n entries {c.xyz, r*r}
     float4* s_mat = lds + P.n_pad;                         // 3*n entries when MAT_LDS
-    float* s_stack = reinterpret_cast<float*>(lds + P.n_pad + (MAT_LDS ? 3 * P.n_pad : 0));
 
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < P.n; i += BLOCK) {
@@ -132,17 +133,18 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform: this wave's private range of task ids
 
-    auto stack_at = [&](uint32_t e, int f) -> float& { return s_stack[(e * kStackFields + f) * BLOCK + tid]; };
+    float4* const gstack = reinterpret_cast<float4*>(P.stack) + ((size_t)blockIdx.x * BLOCK + tid) * (kStackEntries * 4);
+    auto stack_rec = [&](uint32_t e) -> float4* { return gstack + e * 4u; };
 
     for (;;) {
         SPT_STAMP(7)
         // ---- phase A: resume a pending transmitted child (smallpt.cpp:252) ----
         if (!alive && sp > 0) {
             --sp;
-            p.o = mk(stack_at(sp, 0), stack_at(sp, 1), stack_at(sp, 2));
-            p.d = mk(stack_at(sp, 3), stack_at(sp, 4), stack_at(sp, 5));
-            p.w = mk(stack_at(sp, 6), stack_at(sp, 7), stack_at(sp, 8));
-            const uint32_t db = __float_as_uint(stack_at(sp, 9));
+            const float4* rec = stack_rec(sp);
+            const float4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
+            p.o = mk(s0.x, s0.y, s0.z); p.d = mk(s1.x, s1.y, s1.z); p.w = mk(s2.x, s2.y, s2.z);
+            const uint32_t db = __float_as_uint(s0.w);
             p.depth = db & 0xFFFFu; p.branch = db >> 16;
             p.rbase = rng_base(k0, p.branch, p.depth);
             alive = true;
@@ -440,10 +442,11 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                             // transmitted child -> LDS stack; reflected child continues (:251-252)
                             const f3 tw = p.w * (f * Tr);
                             if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
-                                stack_at(sp, 0) = xin.x; stack_at(sp, 1) = xin.y; stack_at(sp, 2) = xin.z;
-                                stack_at(sp, 3) = tdir.x; stack_at(sp, 4) = tdir.y; stack_at(sp, 5) = tdir.z;
-                                stack_at(sp, 6) = tw.x; stack_at(sp, 7) = tw.y; stack_at(sp, 8) = tw.z;
-                                stack_at(sp, 9) = __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16));
+                                float4* rec = stack_rec(sp);
+                                rec[0] = make_float4(xin.x, xin.y, xin.z, __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16)));
+                                rec[1] = make_float4(tdir.x, tdir.y, tdir.z, 0.f);
+                                rec[2] = make_float4(tw.x, tw.y, tw.z, 0.f);
+                                rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);      // completes the 64-byte line
                                 ++sp;
                             }
                             nf = f * Re;
@@ -613,8 +616,11 @@ extern "C" int spt_k_block_threads_for(int mat_lds, int big_block) { return mat_
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block)
 {
     const size_t block = (size_t)spt_k_block_threads_for(mat_lds, big_block);
-    return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u) + (size_t)spt::kStackEntries * spt::kStackFields * block * 4u;
+    (void)block;
+    return (size_t)n_pad * 16u * (mat_lds ? 4u : 1u);
 }
+
+extern "C" size_t spt_k_stack_floats(uint32_t blocks, int block_threads) { return (size_t)blocks * (size_t)block_threads * spt::kStackEntries * 16u; }
 
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream)
 {

@@ -37,7 +37,7 @@ constexpr uint32_t kEpsBias = 0x38D1B717u + 1u;                  // bits(1e-4f) 
 constexpr uint32_t kInfKeyP = 0x60AD78ECu - kEpsBias;            // key of 1e20f
 constexpr int kPoolBlock = 256;
 constexpr uint32_t kNoTask = 0xFFFFFFFFu;
-constexpr int kStackWords = 12;                                  // one pending child = 3 float4: {o, depth|branch<<16} {d, k0} {w, k1}
+constexpr int kStackWords = 16;                                  // one pending child = one 64-byte line: {o, depth|branch<<16} {d, k0} {w, k1} {pad}
 constexpr int kMaxUnroll = 24;                                   // spheres handled by the unrolled closest-hit code
 #ifndef SPT_POOL_NARROW
 #define SPT_POOL_NARROW 1                                        // lane-parallel closest hit for batches of <= 4 rays
@@ -109,9 +109,9 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     }
     __syncthreads();
 
-    // pending transmitted children: [slot][entry] records of 48 contiguous bytes (one 64-byte line per push / pop)
-    float4* const gstack = reinterpret_cast<float4*>(K.stack) + (size_t)wave_gid * (3 * 3 * P);
-    auto stack_rec = [&](uint32_t e, uint32_t slot) -> float4* { return gstack + (slot * 3u + e) * 3u; };
+    // pending transmitted children: [slot][entry] records of one 64-byte line each (48 bytes used, the line is written whole)
+    float4* const gstack = reinterpret_cast<float4*>(K.stack) + (size_t)wave_gid * (3 * 4 * P);
+    auto stack_rec = [&](uint32_t e, uint32_t slot) -> float4* { return gstack + (slot * 3u + e) * 4u; };
 
     const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
     const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                             rec[0] = make_float4(xin.x, xin.y, xin.z, __uint_as_float((depth + 1u) | ((br | (1u << depth) | ((branchf & 8u) | (nonfin ? 8u : 0u))) << 16)));
                             rec[1] = make_float4(tdir.x, tdir.y, tdir.z, __uint_as_float(rbase - ((br << 29) | (depth << 2)) * kGolden));   // k0
                             rec[2] = make_float4(tw.x, tw.y, tw.z, __uint_as_float(k1));
+                            rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);              // completes the line: no partial-line write
                             ++sp;
                         }
                         nf = f * Re;

@@ -18,6 +18,7 @@ i=0
 NP=${SPT_PMC_PASSES:-${#PASSES[@]}}
 for P in "${PASSES[@]}"; do
   [ $i -ge $NP ] && break
+  if [ -n "${SPT_PMC_ONLY:-}" ] && ! echo " $SPT_PMC_ONLY " | grep -q " $i "; then i=$((i+1)); continue; fi
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/${TAG}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $R/gpurun_out/${TAG}_p$i.log; }
   i=$((i+1))
 done
