@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help=argparse.SUPPRESS)   # dev only: kernel A/B (csrc/spt_internal.h)
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # the host driver of this pool only supports dmabuf IPC (RCCL needs it)
     import torch
     import torch.distributed as dist
     import optix_test_smallpt_amd as pkg

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -180,9 +181,20 @@ int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
 // Builds the device tables from the reference-shaped sphere records.  All derived values are single
 // IEEE operations on the host, bit-identical to evaluating them per bounce:
 //   r*r (scene.cpp:133), pmax = fmaxf(color) (smallpt.cpp:177), color*(1/pmax) (smallpt.cpp:192).
+static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n);
+
 int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
 {
     if (!c) return 1;
+    try {
+        return set_scene_impl(c, s, n);
+    } catch (const std::exception& e) {
+        return c->fail("spt_set_scene: %s", e.what());
+    }
+}
+
+static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
+{
     if (n > SPT_MAX_SPHERES) return c->fail("spt_set_scene: %u spheres > SPT_MAX_SPHERES (%u)", n, SPT_MAX_SPHERES);
     if (n && !s) return c->fail("spt_set_scene: spheres is NULL");
     for (uint32_t i = 0; i < n; ++i)
@@ -286,9 +298,20 @@ uint32_t spt_make_sphere_trimesh(const float origin[3], float radius, uint32_t s
     return ni / 3;
 }
 
+static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
+
 int spt_set_meshes(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials)
 {
     if (!c) return 1;
+    try {                                   // host-side tables are std::vectors: no exception may cross the C boundary
+        return set_meshes_impl(c, meshes, nmesh, materials);
+    } catch (const std::exception& e) {
+        return c->fail("spt_set_meshes: %s", e.what());
+    }
+}
+
+static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials)
+{
     if (nmesh && (!meshes || !materials)) return c->fail("spt_set_meshes: NULL argument");
     uint64_t ntris = 0, nverts = 0;
     for (uint32_t i = 0; i < nmesh; ++i) {

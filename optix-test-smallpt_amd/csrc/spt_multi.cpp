@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -175,7 +176,9 @@ int spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi*
     for (int i = 0; i < ndev; ++i)
         for (int j = 0; j < i; ++j)
             if (device_ids[i] == device_ids[j]) { g_multi_create_error = "spt_multi_create: device ids must be distinct"; return 1; }
-    spt_multi* m = new spt_multi;
+    spt_multi* m = nullptr;
+    try {                                   // no exception may cross the C boundary (thread creation, allocations)
+    m = new spt_multi;
     m->flags = flags;
     m->use_rccl = ndev > 1 || (flags & SPT_MULTI_SELF_EXCHANGE);
     m->ranks.resize((size_t)ndev);
@@ -207,15 +210,24 @@ int spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi*
     }
     *out = m;
     return 0;
+    } catch (const std::exception& e) {
+        g_multi_create_error = std::string("spt_multi_create: ") + e.what();
+        if (m) { for (auto& r : m->ranks) delete r.worker; delete m; }
+        return 1;
+    }
 }
 
 int spt_multi_set_scene(spt_multi* m, const spt_sphere* spheres, uint32_t n)
 {
     if (!m) return 1;
+    try {
     return m->on_all([m, spheres, n](int i) {
         Rank& r = m->ranks[(size_t)i];
         if (spt_set_scene(r.ctx, spheres, n)) r.error = spt_last_error(r.ctx);
     });
+    } catch (const std::exception& e) {
+        return m->fail("spt_multi_set_scene: %s", e.what());
+    }
 }
 
 void* spt_multi_framebuffer(spt_multi* m) { return m ? m->d_frame : nullptr; }
@@ -224,6 +236,7 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
                      uint32_t flags, float* out_rgb, spt_multi_stats* stats)
 {
     if (!m) return 1;
+    try {
     if (!cam) return m->fail("spt_multi_render: camera is NULL");
     if (w == 0 || h == 0 || samps == 0) return m->fail("spt_multi_render: empty image or samps == 0");
     const auto t0 = std::chrono::steady_clock::now();
@@ -310,6 +323,9 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return 0;
+    } catch (const std::exception& e) {
+        return m->fail("spt_multi_render: %s", e.what());
+    }
 }
 
 }  // extern "C"
