@@ -8,7 +8,8 @@ from ._lib import (INTERNAL_SYMBOLS, LIB_PATH, MULTI_SYMBOLS, SYMBOLS, SptCamera
 from .renderer import (FLAG_NORMALISE, MultiRenderer, ProgressiveRenderer, Renderer, SptError, pinhole_camera,  # noqa: F401
                        smallpt_camera, to_int, write_ppm)
 from .scene import (DIFF, HIT_DTYPE, RAY_DTYPE, REFR, SPEC, SPHERE_DTYPE, TriMesh, cornell9, make_sphere_trimesh,  # noqa: F401
-                    make_spheres, random_spheres, single_triangle_scene, spheres_from_json, spheres_to_json)
+                    make_spheres, meshes_from_json, meshes_to_json, random_spheres, single_triangle_scene, spheres_from_json,
+                    spheres_to_json)
 
 __all__ = ["Renderer", "MultiRenderer", "ProgressiveRenderer", "SptError", "smallpt_camera", "pinhole_camera", "cornell9", "random_spheres", "make_spheres",
            "spheres_from_json", "spheres_to_json", "SPHERE_DTYPE", "DIFF", "SPEC", "REFR",

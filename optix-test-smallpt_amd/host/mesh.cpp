@@ -17,4 +17,26 @@ TriMesh makeSphereTriMesh(const float3 origin, float radius, const uint32_t subd
     return m;
 }
 
+// Runs the tessellator for every "sphere" entry of a loaded scene (the loader itself is host-only and does not link the
+// library); explicit-buffer entries are left as they are.
+void realize_meshes(Scene& scene)
+{
+    for (MeshInstance& m : scene.meshes)
+        if (m.generator == "sphere" && m.mesh.indexBuffer.empty()) m.mesh = makeSphereTriMesh(m.center, m.radius, m.subdiv);
+}
+
+Scene shipped_two_sphere_mesh_scene()
+{
+    Scene s;   // smallpt.cpp:32-33: Sphere(10, (50,40.8,81.6), 0, (.75,.25,.25), DIFF), Sphere(600, (50,681.6-.27,81.6), (1,1,1), 0, DIFF)
+    MeshInstance a, b;
+    a.generator = b.generator = "sphere";
+    a.center = make_float3(50, 40.8f, 81.6f); a.radius = 10.f;
+    a.material = Material(make_float3(0, 0, 0), make_float3(.75f, .25f, .25f), DIFF);
+    b.center = make_float3(50, (float)(681.6 - .27), 81.6f); b.radius = 600.f;
+    b.material = Material(make_float3(1, 1, 1), make_float3(0, 0, 0), DIFF);
+    s.meshes = {a, b};
+    realize_meshes(s);
+    return s;
+}
+
 }  // namespace spt_host

@@ -195,24 +195,75 @@ double number(const JValue& v, const char* what)
 
 }  // namespace
 
+namespace {
+Refl_t parse_refl(const JValue& r)
+{
+    if (r.kind == JValue::String) {
+        if (r.str == "DIFF") return DIFF;
+        if (r.str == "SPEC") return SPEC;
+        if (r.str == "REFR") return REFR;
+        throw std::runtime_error("scene JSON: refl must be DIFF, SPEC or REFR");
+    }
+    const int k = (int)number(r, "refl");
+    if (k < 0 || k > 2) throw std::runtime_error("scene JSON: refl must be 0, 1 or 2");
+    return (Refl_t)k;
+}
+std::vector<float3> vec3_list(const JValue& v, const char* what)
+{
+    if (v.kind != JValue::Array) throw std::runtime_error(std::string("scene JSON: \"") + what + "\" must be an array of 3-number arrays");
+    std::vector<float3> out;
+    out.reserve(v.arr.size());
+    for (auto& e : v.arr) out.push_back(vec3(*e, what));
+    return out;
+}
+}  // namespace
+
+// Host-only part of the mesh loader: everything except running the tessellator (mesh.cpp fills `mesh` of "sphere" entries).
+static void load_meshes(const JValue& root, Scene& sc)
+{
+    auto it = root.obj.find("meshes");
+    if (it == root.obj.end()) return;
+    if (it->second->kind != JValue::Array) throw std::runtime_error("scene JSON: \"meshes\" must be an array");
+    for (auto& e : it->second->arr) {
+        MeshInstance mi;
+        mi.material = Material(vec3(member(*e, "emission"), "emission"), vec3(member(*e, "color"), "color"), parse_refl(member(*e, "refl")));
+        auto sp = e->obj.find("sphere");
+        if (sp != e->obj.end()) {
+            mi.generator = "sphere";
+            mi.center = vec3(member(*sp->second, "center"), "center");
+            mi.radius = (float)number(member(*sp->second, "radius"), "radius");
+            if (sp->second->obj.count("subdiv")) {
+                const double sd = number(member(*sp->second, "subdiv"), "subdiv");
+                if (!(sd >= 1 && sd <= 2048)) throw std::runtime_error("scene JSON: subdiv must be in 1..2048");
+                mi.subdiv = (uint32_t)sd;
+            }
+        } else {
+            mi.mesh.positionBuffer = vec3_list(member(*e, "positions"), "positions");
+            mi.mesh.normalBuffer = vec3_list(member(*e, "normals"), "normals");
+            if (mi.mesh.normalBuffer.size() != mi.mesh.positionBuffer.size()) throw std::runtime_error("scene JSON: positions and normals differ in length");
+            for (const float3& t : vec3_list(member(*e, "indices"), "indices")) {
+                for (float f : {t.x, t.y, t.z}) {
+                    if (!(f >= 0 && f < (float)mi.mesh.positionBuffer.size()) || f != (float)(uint32_t)f) throw std::runtime_error("scene JSON: triangle index out of range");
+                    mi.mesh.indexBuffer.push_back((uint32_t)f);
+                }
+            }
+        }
+        sc.meshes.push_back(std::move(mi));
+    }
+}
+
 Scene load_scene_json(const std::string& text)
 {
     Parser p(text);
     JPtr root = p.parse();
     Scene sc;
-    const JValue& spheres = member(*root, "spheres");
+    if (root->kind != JValue::Object) throw std::runtime_error("scene JSON: expected an object");
+    load_meshes(*root, sc);
+    static const JValue no_spheres = [] { JValue v; v.kind = JValue::Array; return v; }();
+    const JValue& spheres = (sc.meshes.empty() || root->obj.count("spheres")) ? member(*root, "spheres") : no_spheres;
     if (spheres.kind != JValue::Array) throw std::runtime_error("scene JSON: \"spheres\" must be an array");
     for (auto& e : spheres.arr) {
-        const JValue& r = member(*e, "refl");
-        Refl_t refl;
-        if (r.kind == JValue::String) {
-            if (r.str == "DIFF") refl = DIFF; else if (r.str == "SPEC") refl = SPEC; else if (r.str == "REFR") refl = REFR;
-            else throw std::runtime_error("scene JSON: refl must be DIFF, SPEC or REFR");
-        } else {
-            const int k = (int)number(r, "refl");
-            if (k < 0 || k > 2) throw std::runtime_error("scene JSON: refl must be 0, 1 or 2");
-            refl = (Refl_t)k;
-        }
+        const Refl_t refl = parse_refl(member(*e, "refl"));
         sc.spheres.emplace_back((float)number(member(*e, "radius"), "radius"), vec3(member(*e, "center"), "center"),
                                 vec3(member(*e, "emission"), "emission"), vec3(member(*e, "color"), "color"), refl);
     }
@@ -268,7 +319,34 @@ std::string scene_to_json(const Scene& scene)
         o << ", \"color\": "; v3(s.material.color);
         o << ", \"refl\": \"" << names[s.material.refl] << "\"}";
     }
-    o << "]}";
+    o << "]";
+    if (!scene.meshes.empty()) {
+        o << ", \"meshes\": [";
+        for (size_t i = 0; i < scene.meshes.size(); ++i) {
+            const MeshInstance& m = scene.meshes[i];
+            o << (i ? ", " : "") << "{";
+            if (m.generator == "sphere") {
+                o << "\"sphere\": {\"center\": "; v3(m.center);
+                o << ", \"radius\": " << m.radius << ", \"subdiv\": " << m.subdiv << "}";
+            } else {
+                auto list = [&](const char* key, const std::vector<float3>& v) {
+                    o << "\"" << key << "\": [";
+                    for (size_t k = 0; k < v.size(); ++k) { if (k) o << ", "; v3(v[k]); }
+                    o << "]";
+                };
+                list("positions", m.mesh.positionBuffer); o << ", "; list("normals", m.mesh.normalBuffer);
+                o << ", \"indices\": [";
+                for (size_t k = 0; k + 2 < m.mesh.indexBuffer.size(); k += 3)
+                    o << (k ? ", " : "") << "[" << m.mesh.indexBuffer[k] << ", " << m.mesh.indexBuffer[k + 1] << ", " << m.mesh.indexBuffer[k + 2] << "]";
+                o << "]";
+            }
+            o << ", \"emission\": "; v3(m.material.emission);
+            o << ", \"color\": "; v3(m.material.color);
+            o << ", \"refl\": \"" << names[m.material.refl] << "\"}";
+        }
+        o << "]";
+    }
+    o << "}";
     return o.str();
 }
 

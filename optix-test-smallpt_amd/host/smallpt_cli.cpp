@@ -3,7 +3,7 @@
 // prints the reference's "Elapsed time" line (:373) and writes ./image.ppm through flipY + writeImage
 // (:375-376).  Extra options select the scene file (JSON), the image size and the device.
 //
-//   smallpt_mi355x [spp] [--scene file.json] [--size WxH] [--seed N] [--out image.ppm] [--device D]
+//   smallpt_mi355x [spp] [--scene file.json | shipped-meshes] [--size WxH] [--seed N] [--out image.ppm] [--device D]
 //                  [--dump-scene out.json] [--parse-only]
 //                  [--devices 0,1,...] [--self-exchange]      row bands over several GPUs + RCCL exchange (MultiRenderer)
 //   smallpt_mi355x [spp] --viewer [--frames N] [--request JSON] [--frames-after M] [--threaded] [--org x,y,z]
@@ -69,7 +69,14 @@ int main(int argc, char* argv[])
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
-        Scene scene = scene_path.empty() ? cornell9() : load_scene_file(scene_path);
+        Scene scene = scene_path.empty() ? cornell9() : (scene_path == "shipped-meshes" ? shipped_two_sphere_mesh_scene() : load_scene_file(scene_path));
+        realize_meshes(scene);
+        auto upload = [&](Renderer& rr) {          // spheres, or the Intersector seam for a mesh scene
+            if (scene.meshes.empty()) { rr.setScene(scene.spheres); return; }
+            std::vector<TriMesh> ms; std::vector<Material> mats;
+            for (const MeshInstance& m : scene.meshes) { ms.push_back(m.mesh); mats.push_back(m.material); }
+            rr.setMeshes(ms, mats);
+        };
         if (!dump_path.empty()) {
             std::ofstream f(dump_path);
             f << scene_to_json(scene) << "\n";
@@ -93,7 +100,7 @@ int main(int argc, char* argv[])
                 const std::vector<Hit> hit = renderer.traceRays(&probe, 1);
                 std::fprintf(stderr, "traceRays probe: dist %.9g uv (%.9g, %.9g) hit %d\n", hit[0].dist, hit[0].uv[0], hit[0].uv[1], (int)(bool)hit[0]);
             } else {
-                renderer.setScene(scene.spheres);
+                upload(renderer);
             }
             Camera camera = defaultViewerCamera();
             if (have_org) camera.org = make_float3(org[0], org[1], org[2]);
@@ -146,7 +153,7 @@ int main(int argc, char* argv[])
             return 0;
         }
         Renderer renderer(device);
-        renderer.setScene(scene.spheres);
+        upload(renderer);
         std::vector<float3> c = renderer.render(cam, (size_t)w, (size_t)h, (size_t)samps, (size_t)seed, /*normalise=*/true);
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
         const spt_stats& st = renderer.stats();

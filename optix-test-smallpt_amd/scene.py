@@ -142,3 +142,45 @@ def single_triangle_scene():
     """SingleTriangleScene of the reference's main() (smallpt.cpp:818-832): one triangle, material emission (1,0,0), DIFF."""
     mesh = TriMesh([(-0.5, -0.5, -2), (0.5, -0.5, -2), (0, 0.5, -2)], [(1, 0, 0), (0, 1, 0), (0, 0, 1)], [(0, 1, 2)])
     return [mesh], [((1, 0, 0), (0, 0, 0), DIFF)]
+
+
+def meshes_to_json(meshes, materials, generators=None, camera=None, spheres=None):
+    """Scene file with a "meshes" array (host/scene.hpp): entry i is {"sphere": {"center", "radius", "subdiv"}} when
+    generators[i] = (center, radius, subdiv) (re-tessellated by the loader with makeSphereTriMesh) or explicit
+    "positions"/"normals"/"indices" buffers, plus the instance's material."""
+    out = []
+    for i, (m, (e, col, refl)) in enumerate(zip(meshes, materials)):
+        ent = {}
+        gen = generators[i] if generators is not None else None
+        if gen is not None:
+            c, r, sd = gen
+            ent["sphere"] = {"center": [float(np.float32(v)) for v in c], "radius": float(np.float32(r)), "subdiv": int(sd)}
+        else:
+            ent["positions"] = [[float(v) for v in p] for p in m.positions]
+            ent["normals"] = [[float(v) for v in p] for p in m.normals]
+            ent["indices"] = [[int(v) for v in t] for t in m.indices]
+        ent["emission"] = [float(np.float32(v)) for v in e]
+        ent["color"] = [float(np.float32(v)) for v in col]
+        ent["refl"] = REFL_NAMES[int(refl)]
+        out.append(ent)
+    doc = {"meshes": out}
+    if spheres is not None:
+        doc["spheres"] = json.loads(spheres_to_json(spheres))["spheres"]
+    if camera is not None:
+        doc["camera"] = camera
+    return json.dumps(doc)
+
+
+def meshes_from_json(text):
+    """Inverse of meshes_to_json: returns (meshes, materials); "sphere" entries are tessellated with make_sphere_trimesh."""
+    doc = json.loads(text)
+    meshes, mats = [], []
+    for ent in doc.get("meshes", []):
+        if "sphere" in ent:
+            g = ent["sphere"]
+            meshes.append(make_sphere_trimesh(g["center"], g["radius"], g.get("subdiv", 32)))
+        else:
+            meshes.append(TriMesh(ent["positions"], ent["normals"], ent["indices"]))
+        refl = ent["refl"]
+        mats.append((tuple(ent["emission"]), tuple(ent["color"]), REFL_IDS[refl] if isinstance(refl, str) else int(refl)))
+    return meshes, mats
