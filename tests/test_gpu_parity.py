@@ -343,6 +343,20 @@ def test_config5_1024_spheres_through_json_loader_full_size(pkg, renderer, oracl
     _rows_match(oracle, sc, img, w, h, samps, seed, (100, 600))
 
 
+def test_kernel_watchdog_reports_instead_of_hanging(pkg):
+    """The pool kernel's watchdog (csrc/spt_internal.h): a launch that exceeds its time budget ends with an error from
+    spt_sync, never with an incomplete image or a hung GPU; the context stays usable."""
+    r = pkg.Renderer(0)
+    r.set_scene(pkg.cornell9())
+    r.set_watchdog(1e-7)                       # 0.24 ticks: every wave gives up at its first check (256 batches in)
+    with pytest.raises(pkg.SptError, match="watchdog"):
+        r.render(512, 384, 64)
+    r.set_watchdog(0)
+    img, st = r.render(32, 24, 2)
+    assert np.isfinite(img).all() and st["samples"] == 32 * 24 * 8
+    r.close()
+
+
 def test_error_behaviour(pkg):
     r = pkg.Renderer(0)
     with pytest.raises(pkg.SptError, match="no scene"):
