@@ -138,6 +138,9 @@ def main():
             dist.init_process_group(backend)
 
     h = H_PER_GPU * world
+    # N > 1: the rows are dealt out round-robin in blocks of 16 rows (every rank renders 768 of the 768*N rows): contiguous
+    # bands of this image differ by up to 1.24x in cost (tools/probe_band_balance.py), interleaved blocks do not
+    interleave = 16 if world > 1 else 0
     begin, count = row_band(h, world, rank)
     samps = args.samps
     r = pkg.Renderer(dev_index)
@@ -146,12 +149,16 @@ def main():
         r.set_tuning(0, args.variant)
     # destination memory of the exchange: rank 0 owns the whole framebuffer and renders its band in place, the other
     # ranks render into their band tensor; the bands are received straight into the framebuffer's row slices
-    fa = FrameAssembler(W, h, device=dev if backend == "nccl" else "cpu")
+    fa = FrameAssembler(W, h, device=dev if backend == "nccl" else "cpu", interleave=interleave)
+    count = fa.count
     band = fa.band if backend == "nccl" else torch.empty((count, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        r.render_rows_device(band, W, h, begin, count, samps, seed=0, normalise=True, stream=stream)
+        if interleave:
+            r.render_interleaved_device(band, W, h, interleave, world, rank, samps, seed=0, normalise=True, stream=stream)
+        else:
+            r.render_rows_device(band, W, h, begin, count, samps, seed=0, normalise=True, stream=stream)
         if world > 1 and backend != "nccl":
             st = r.sync()
             fa.band.copy_(band)          # rehearsal transport: through host memory
@@ -223,6 +230,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Cornell-9 (9 spheres), {W}x{H_PER_GPU} per GPU, {4 * samps} spp, seed 0, "
                                    f"smallpt camera + 2x2 tent filter; image {W}x{h} row-tiled over {world} GPU(s)"
+                                   + (f" (rows dealt out round-robin in blocks of {interleave})" if interleave else "")
                                    + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0 each step" if world > 1 else ""),
                        "spheres": N_SPHERES, "width": W, "height": h, "spp": 4 * samps, "rows_per_gpu": count},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

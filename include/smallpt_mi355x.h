@@ -159,6 +159,15 @@ int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uin
  * enqueued on hip_stream (NULL = the context's stream).  Display weight = 1/(frames*spp) (smallpt.cpp:957). */
 int  spt_accumulate_device(spt_ctx* ctx, void* d_accum, const void* d_frame, uint64_t n, int clear, void* hip_stream);
 
+/* The same for a rank of a multi-GPU render whose rows are dealt out round-robin in blocks of `block_rows` rows (a power of
+ * two): block t of the image (rows [t*B, (t+1)*B)) belongs to rank t % world.  Contiguous bands of a Cornell-like image
+ * differ by up to 1.34x in cost (floor and spheres below, ceiling above); interleaved blocks balance the ranks.  d_out_rgb
+ * receives this rank's spt_interleaved_row_count() rows packed in ascending row order. */
+uint32_t spt_interleaved_row_count(uint32_t h, uint32_t block_rows, uint32_t world, uint32_t rank);
+int  spt_render_interleaved_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t block_rows,
+                                   uint32_t world, uint32_t rank, uint32_t samps_per_cell, uint64_t seed, uint32_t flags,
+                                   void* d_out_rgb, void* hip_stream);
+
 /* The render thread's frame loop (smallpt.cpp:895-942) with accumBuffer (:881-883) resident in HBM behind the boundary:
  *   spt_progressive_begin    allocates the w*h*3 accumulation buffer and a frame buffer on the context's device;
  *   spt_progressive_frame    = `outImage = renderer.render(camera, ..., sampleCountPerJitterCell, threadCount, seed)` (:922,

@@ -5,15 +5,17 @@
  * smallpt.cpp:480-481) behind `Vector<float3> Renderer::render(...)` (smallpt.cpp:679-680,692-814; sole caller :922).
  * This entry point keeps that call shape -- one call, one framebuffer -- and spreads it over the GPUs of one node:
  *
- *   * the image is split into contiguous row bands, band g = rows [g*h/G ...) (the reference's own unit of
- *     parallelism is the row, smallpt.cpp:317,736); the RNG is keyed by the GLOBAL pixel index, so the assembled image
- *     is bit-identical for every device count;
+ *   * the image rows are dealt out to the devices round-robin in blocks of 16 rows (the reference's own unit of
+ *     parallelism is the row, smallpt.cpp:317,736; contiguous bands of a Cornell-like image differ by up to 1.34x in cost,
+ *     so SPT_MULTI_CONTIGUOUS -- band g = rows [g*h/G ...) -- is only an option); the RNG is keyed by the GLOBAL pixel
+ *     index, so the assembled image is bit-identical for every device count and either partition;
  *   * one host thread + one spt_ctx + one HIP stream per device; every device renders its band with
  *     spt_render_rows_device (include/smallpt_mi355x.h);
  *   * the bands are assembled on the root device (device_ids[0]) by ONE exchange step: every other rank ncclSend()s
- *     its rows, the root ncclRecv()s each band straight into its row-slice of the framebuffer, all receives fused in
- *     one ncclGroupStart/End -- point-to-point over xGMI, 7 links into the root in parallel, no ring, no reduction.
- *     The root's own band is rendered in place.  With one device no RCCL communicator is created at all
+ *     its packed rows, the root ncclRecv()s them (all receives fused in one ncclGroupStart/End -- point-to-point over xGMI,
+ *     7 links into the root in parallel, no ring, no reduction) and scatters the row blocks into the framebuffer with one
+ *     strided device copy per rank; with contiguous bands the receives land straight in the framebuffer's row slices and
+ *     the root's own band is rendered in place.  With one device no RCCL communicator is created at all
  *     (unless SPT_MULTI_SELF_EXCHANGE is passed, which routes the root's band through a grouped self send/recv:
  *     a rehearsal of the RCCL path for boxes with a single GPU).
  *
@@ -31,6 +33,9 @@ extern "C" {
 typedef struct spt_multi spt_multi;
 
 #define SPT_MULTI_SELF_EXCHANGE 1u  /* create flag: with one device, still send the band through RCCL (self send/recv) */
+#define SPT_MULTI_COPY_EXCHANGE 4u  /* create flag: assemble with hipMemcpyPeerAsync pulls by the root instead of RCCL; with this
+                                       transport several ranks may share a device (device ids may repeat) */
+#define SPT_MULTI_CONTIGUOUS    2u  /* create flag: contiguous row bands instead of round-robin blocks of 16 rows */
 
 typedef struct spt_multi_stats {
     uint64_t samples;          /* whole image */
@@ -43,7 +48,7 @@ typedef struct spt_multi_stats {
     uint32_t pad;
 } spt_multi_stats;
 
-/* device_ids[0] is the root (the framebuffer is assembled there).  ndev >= 1; ids must be distinct. */
+/* device_ids[0] is the root (the framebuffer is assembled there).  ndev >= 1; ids must be distinct (RCCL transport). */
 int  spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi** out);
 void spt_multi_destroy(spt_multi* m);
 const char* spt_multi_last_error(const spt_multi* m);   /* m may be NULL: last error of spt_multi_create */

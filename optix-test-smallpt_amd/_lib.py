@@ -54,6 +54,9 @@ SYMBOLS = {
                              C.c_uint32, _P, C.POINTER(SptStats)]),
     "spt_render_rows_device": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
+    "spt_interleaved_row_count": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "spt_render_interleaved_device": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
     "spt_accumulate_device": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _P]),
     "spt_progressive_begin": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_progressive_frame": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint64, C.c_int, C.POINTER(SptStats)]),

@@ -431,15 +431,54 @@ int spt_camera_pinhole(const float vx[3], const float vy[3], const float vz[3], 
     return 0;
 }
 
+static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+                            uint32_t rb_log2, uint32_t rb_stride, uint32_t rb_mask, uint32_t samps, uint64_t seed,
+                            uint32_t flags, void* d_out_rgb, void* hip_stream);
+
 int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h,
                            uint32_t row_begin, uint32_t row_count, uint32_t samps, uint64_t seed,
                            uint32_t flags, void* d_out_rgb, void* hip_stream)
 {
     if (!c) return 1;
+    if (row_count == 0 || (uint64_t)row_begin + row_count > h) return c->fail("spt_render_rows_device: row band [%u,+%u) outside image height %u", row_begin, row_count, h);
+    return render_rows_impl(c, cam, w, h, row_begin, row_count, 0u, 1u, 0u, samps, seed, flags, d_out_rgb, hip_stream);
+}
+
+// Rows dealt out round-robin in blocks of `block_rows` rows: block t of the image (rows [t*B, (t+1)*B)) belongs to rank t % world.
+uint32_t spt_interleaved_row_count(uint32_t h, uint32_t block_rows, uint32_t world, uint32_t rank)
+{
+    if (!block_rows || !world || rank >= world) return 0;
+    const uint32_t nblk = (h + block_rows - 1) / block_rows;            // blocks of the image, the last one may be short
+    if (rank >= nblk) return 0;
+    const uint32_t mine = (nblk - 1 - rank) / world + 1;                 // blocks rank, rank + world, ...
+    uint32_t rows = mine * block_rows;
+    const uint32_t last = rank + (mine - 1) * world;                     // this rank's last block
+    if (last == nblk - 1) rows -= nblk * block_rows - h;                 // ... is the image's short last block
+    return rows;
+}
+
+int spt_render_interleaved_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t block_rows,
+                                  uint32_t world, uint32_t rank, uint32_t samps, uint64_t seed, uint32_t flags,
+                                  void* d_out_rgb, void* hip_stream)
+{
+    if (!c) return 1;
+    if (!block_rows || (block_rows & (block_rows - 1))) return c->fail("spt_render_interleaved_device: block_rows must be a power of two");
+    if (!world || rank >= world) return c->fail("spt_render_interleaved_device: rank %u of %u", rank, world);
+    if ((uint64_t)world * block_rows > 0x7FFFFFFFull) return c->fail("spt_render_interleaved_device: world * block_rows too large");
+    const uint32_t rows = spt_interleaved_row_count(h, block_rows, world, rank);
+    if (rows == 0) return c->fail("spt_render_interleaved_device: rank %u owns no rows of a %u-row image", rank, h);
+    uint32_t lb = 0;
+    while ((1u << lb) < block_rows) ++lb;
+    return render_rows_impl(c, cam, w, h, rank * block_rows, rows, lb, world * block_rows, block_rows - 1u, samps, seed, flags, d_out_rgb, hip_stream);
+}
+
+static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_count,
+                            uint32_t rb_log2, uint32_t rb_stride, uint32_t rb_mask, uint32_t samps, uint64_t seed,
+                            uint32_t flags, void* d_out_rgb, void* hip_stream)
+{
     if (!cam || !d_out_rgb) return c->fail("spt_render_rows_device: NULL argument");
     if (w == 0 || h == 0 || samps == 0) return c->fail("spt_render_rows_device: empty image or samps == 0");
     if ((uint64_t)w * h > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: w*h exceeds 2^32-1 pixels");
-    if (row_count == 0 || (uint64_t)row_begin + row_count > h) return c->fail("spt_render_rows_device: row band [%u,+%u) outside image height %u", row_begin, row_count, h);
     if ((uint64_t)samps * 4 > 0xFFFFFFFFull) return c->fail("spt_render_rows_device: spp overflows 32 bits");
     const uint64_t npix = (uint64_t)row_count * w;
     // D9: a jitter cell's samples are accumulated in nb = 1, 2, 4 or 8 blocks (>= 16 samples each); one task = one block
@@ -466,6 +505,7 @@ int spt_render_rows_device(spt_ctx* c, const spt_camera* cam, uint32_t w, uint32
     P.sampler = cam->sampler;
     P.inv_wf = 1.f / (float)w; P.inv_hf = 1.f / (float)h;   // pixelSize, smallpt.cpp:746
     P.w = w; P.h = h; P.row_begin = row_begin; P.row_count = row_count;
+    P.rb_log2 = rb_log2; P.rb_stride = rb_stride; P.rb_mask = rb_mask;
     P.inv_w = 1.0 / (double)w; P.inv_h = 1.0 / (double)h;
     P.samps = samps; P.ntasks = (uint32_t)ntasks;
     P.nb_log2 = nb_log2; P.sb = (samps + nb - 1u) / nb;

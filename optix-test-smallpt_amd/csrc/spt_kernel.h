@@ -15,6 +15,9 @@ struct KParams {
     float inv_wf, inv_hf;    // 1.f/w, 1.f/h (pixelSize, smallpt.cpp:746)
     // image / band
     uint32_t w, h, row_begin, row_count;
+    // local row ry of this launch is image row row_begin + (ry >> rb_log2) * rb_stride + (ry & rb_mask): a contiguous band
+    // is (0, 1, 0); rows dealt out round-robin in blocks of B = 2^rb_log2 rows to `world` ranks are (log2 B, world * B, B - 1)
+    uint32_t rb_log2, rb_stride, rb_mask;
     double inv_w, inv_h;     // RN(1/w), RN(1/h) for the exact double division of smallpt.cpp:331-332
     uint32_t samps;          // samples per jitter cell (spp = 4*samps)
     uint32_t ntasks;         // 4 * row_count * w * nb: one task = one block of a jitter cell's samples (D9)

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                     cell = cellid & 3u;
                     const uint32_t ry = pix_local / P.w;
                     px = pix_local - ry * P.w;
-                    py = P.row_begin + ry;
+                    py = P.row_begin + (ry >> P.rb_log2) * P.rb_stride + (ry & P.rb_mask);      // contiguous band or interleaved row blocks
                     const uint32_t pixel_idx = py * P.w + px;          // GLOBAL index (smallpt.cpp:298)
                     p0 = mix32(pixel_idx + P.s0);
                     p1 = mix32(pixel_idx ^ P.s1);

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
                 const uint32_t pix_local = cellid >> 2;
                 cell = cellid & 3u;
                 const uint32_t ry = pix_local / K.w;
-                px = pix_local - ry * K.w; py = K.row_begin + ry;
+                px = pix_local - ry * K.w; py = K.row_begin + (ry >> K.rb_log2) * K.rb_stride + (ry & K.rb_mask);
                 const uint32_t pixel_idx = py * K.w + px;                        // GLOBAL index (smallpt.cpp:298)
                 p0 = mix32(pixel_idx + K.s0); p1 = mix32(pixel_idx ^ K.s1);
                 s_gen = blk * K.sb;

@@ -98,6 +98,8 @@ struct spt_multi {
     bool use_rccl = false;
     float* d_frame = nullptr;      // root device: w*h*3 floats
     size_t frame_cap = 0;
+    float* d_staging = nullptr;    // root device, interleaved partition: the other ranks' packed rows before the scatter
+    size_t staging_cap = 0;
     std::string error;
 
     int fail(const char* fmt, ...)
@@ -158,6 +160,7 @@ void spt_multi_destroy(spt_multi* m)
             if (r.comm) (void)ncclCommDestroy(r.comm);
             if (r.d_band) (void)hipFree(r.d_band);
             if (i == 0 && m->d_frame) (void)hipFree(m->d_frame);
+            if (i == 0 && m->d_staging) (void)hipFree(m->d_staging);
             if (r.ev_a) (void)hipEventDestroy(r.ev_a);
             if (r.ev_b) (void)hipEventDestroy(r.ev_b);
             if (r.stream) (void)hipStreamDestroy(r.stream);
@@ -173,14 +176,15 @@ int spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi*
     if (!out) { g_multi_create_error = "spt_multi_create: out is NULL"; return 1; }
     *out = nullptr;
     if (!device_ids || ndev < 1) { g_multi_create_error = "spt_multi_create: need at least one device id"; return 1; }
-    for (int i = 0; i < ndev; ++i)
-        for (int j = 0; j < i; ++j)
-            if (device_ids[i] == device_ids[j]) { g_multi_create_error = "spt_multi_create: device ids must be distinct"; return 1; }
+    if (!(flags & SPT_MULTI_COPY_EXCHANGE))      // RCCL needs one device per rank; the copy transport also runs ranks that share a device
+        for (int i = 0; i < ndev; ++i)
+            for (int j = 0; j < i; ++j)
+                if (device_ids[i] == device_ids[j]) { g_multi_create_error = "spt_multi_create: device ids must be distinct"; return 1; }
     spt_multi* m = nullptr;
     try {                                   // no exception may cross the C boundary (thread creation, allocations)
     m = new spt_multi;
     m->flags = flags;
-    m->use_rccl = ndev > 1 || (flags & SPT_MULTI_SELF_EXCHANGE);
+    m->use_rccl = !(flags & SPT_MULTI_COPY_EXCHANGE) && (ndev > 1 || (flags & SPT_MULTI_SELF_EXCHANGE));
     m->ranks.resize((size_t)ndev);
     for (int i = 0; i < ndev; ++i) {
         m->ranks[(size_t)i].device = device_ids[i];
@@ -244,11 +248,26 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
     const size_t nfl = (size_t)w * h * 3;
     const bool self_exchange = world == 1 && m->use_rccl;
 
-    // 1. buffers + band render, every device on its own thread (bands with zero rows -- more devices than rows -- skip)
-    int rc = m->on_all([=](int i) {
+    // Row partition: contiguous bands (SPT_MULTI_CONTIGUOUS, or a single device) or -- default -- rows dealt out round-robin
+    // in blocks of kBlockRows rows, which balances the ranks (contiguous bands of a Cornell-like image differ by up to 1.34x).
+    constexpr uint32_t kBlockRows = 16;
+    const bool interleaved = world > 1 && !(m->flags & SPT_MULTI_CONTIGUOUS);
+    auto rows_of = [=](uint32_t p, uint32_t* begin) -> uint32_t {
+        uint32_t b = 0, c = 0;
+        if (interleaved) c = spt_interleaved_row_count(h, kBlockRows, world, p);
+        else spt_multi_row_band(h, world, p, &b, &c);
+        if (begin) *begin = b;
+        return c;
+    };
+    // staging offsets (in floats) of the ranks' packed rows on the root, interleaved mode
+    std::vector<size_t> stage_off(world + 1, 0);
+    for (uint32_t p = 0; p < world; ++p) stage_off[p + 1] = stage_off[p] + (interleaved && p != 0 ? (size_t)rows_of(p, nullptr) * w * 3 : 0);
+
+    // 1. buffers + band render, every device on its own thread (ranks without rows -- more devices than rows -- skip)
+    int rc = m->on_all([=, &stage_off](int i) {
         Rank& r = m->ranks[(size_t)i];
-        uint32_t begin, count;
-        spt_multi_row_band(h, world, (uint32_t)i, &begin, &count);
+        uint32_t begin = 0;
+        const uint32_t count = rows_of((uint32_t)i, &begin);
         RK_HIP(r, hipSetDevice(r.device));
         if (i == 0 && nfl > m->frame_cap) {
             if (m->d_frame) (void)hipFree(m->d_frame);
@@ -256,10 +275,16 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
             RK_HIP(r, hipMalloc(reinterpret_cast<void**>(&m->d_frame), nfl * sizeof(float)));
             m->frame_cap = nfl;
         }
+        if (i == 0 && stage_off[world] > m->staging_cap) {
+            if (m->d_staging) (void)hipFree(m->d_staging);
+            m->d_staging = nullptr; m->staging_cap = 0;
+            RK_HIP(r, hipMalloc(reinterpret_cast<void**>(&m->d_staging), stage_off[world] * sizeof(float)));
+            m->staging_cap = stage_off[world];
+        }
         const size_t band_fl = (size_t)count * w * 3;
         float* dst;
-        if (i == 0 && !self_exchange) {
-            dst = m->d_frame + (size_t)begin * w * 3;          // the root's band is rendered in place
+        if (i == 0 && !self_exchange && !interleaved) {
+            dst = m->d_frame + (size_t)begin * w * 3;          // contiguous: the root's band is rendered in place
         } else {
             if (band_fl > r.band_cap) {
                 if (r.d_band) (void)hipFree(r.d_band);
@@ -271,7 +296,10 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
         }
         r.stats = spt_stats{};
         if (count) {
-            if (spt_render_rows_device(r.ctx, cam, w, h, begin, count, samps, seed, flags, dst, r.stream)) { r.error = spt_last_error(r.ctx); return; }
+            const int e = interleaved
+                ? spt_render_interleaved_device(r.ctx, cam, w, h, kBlockRows, world, (uint32_t)i, samps, seed, flags, dst, r.stream)
+                : spt_render_rows_device(r.ctx, cam, w, h, begin, count, samps, seed, flags, dst, r.stream);
+            if (e) { r.error = spt_last_error(r.ctx); return; }
         }
         // 2. the exchange step, enqueued behind the render on the same stream
         r.gather_ms = 0.f;
@@ -280,12 +308,29 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
             if (i == 0) {
                 RK_NCCL(r, ncclGroupStart());
                 for (uint32_t p = self_exchange ? 0u : 1u; p < world; ++p) {
-                    uint32_t pb, pc;
-                    spt_multi_row_band(h, world, p, &pb, &pc);
-                    if (pc) RK_NCCL(r, ncclRecv(m->d_frame + (size_t)pb * w * 3, (size_t)pc * w * 3, ncclFloat, (int)p, r.comm, r.stream));
+                    uint32_t pb = 0;
+                    const uint32_t pc = rows_of(p, &pb);
+                    float* to = interleaved ? m->d_staging + stage_off[p] : m->d_frame + (size_t)pb * w * 3;
+                    if (pc) RK_NCCL(r, ncclRecv(to, (size_t)pc * w * 3, ncclFloat, (int)p, r.comm, r.stream));
                 }
                 if (self_exchange && count) RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
                 RK_NCCL(r, ncclGroupEnd());
+                if (interleaved) {
+                    // scatter every rank's packed row blocks to their rows: block k of rank p starts at row (k * world + p) * B
+                    for (uint32_t p = 0; p < world; ++p) {
+                        const uint32_t pc = rows_of(p, nullptr);
+                        if (!pc) continue;
+                        const float* from = p == 0 ? r.d_band : m->d_staging + stage_off[p];
+                        const size_t block_bytes = (size_t)kBlockRows * w * 3 * sizeof(float);
+                        const uint32_t full = pc / kBlockRows, rest = pc % kBlockRows;
+                        if (full)
+                            RK_HIP(r, hipMemcpy2DAsync(m->d_frame + (size_t)p * kBlockRows * w * 3, block_bytes * world, from, block_bytes,
+                                                       block_bytes, full, hipMemcpyDeviceToDevice, r.stream));
+                        if (rest)
+                            RK_HIP(r, hipMemcpyAsync(m->d_frame + ((size_t)full * world + p) * kBlockRows * w * 3, from + (size_t)full * kBlockRows * w * 3,
+                                                     (size_t)rest * w * 3 * sizeof(float), hipMemcpyDeviceToDevice, r.stream));
+                    }
+                }
             } else if (count) {
                 RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
             }
@@ -296,6 +341,47 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
         if (m->use_rccl) RK_HIP(r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
     });
     if (rc) return rc;
+
+    // 2'. copy transport (SPT_MULTI_COPY_EXCHANGE): every rank has finished its rows (stream synchronised above); the root
+    // pulls the packed rows with peer copies and scatters / places them exactly like the RCCL path does.
+    if (!m->use_rccl && world > 1) {
+        Rank& r0 = m->ranks[0];
+        r0.error.clear();
+        r0.worker->submit([&] {
+            Rank& r = r0;
+            RK_HIP(r, hipSetDevice(r.device));
+            RK_HIP(r, hipEventRecord(r.ev_a, r.stream));
+            for (uint32_t p = 0; p < world; ++p) {
+                uint32_t pb = 0;
+                const uint32_t pc = rows_of(p, &pb);
+                if (!pc) continue;
+                const Rank& src = m->ranks[p];
+                if (!interleaved) {
+                    if (p == 0) continue;                      // rendered in place
+                    RK_HIP(r, hipMemcpyPeerAsync(m->d_frame + (size_t)pb * w * 3, r.device, src.d_band, src.device, (size_t)pc * w * 3 * sizeof(float), r.stream));
+                    continue;
+                }
+                const float* from = src.d_band;
+                if (p != 0) {
+                    RK_HIP(r, hipMemcpyPeerAsync(m->d_staging + stage_off[p], r.device, src.d_band, src.device, (size_t)pc * w * 3 * sizeof(float), r.stream));
+                    from = m->d_staging + stage_off[p];
+                }
+                const size_t block_bytes = (size_t)kBlockRows * w * 3 * sizeof(float);
+                const uint32_t full = pc / kBlockRows, rest = pc % kBlockRows;
+                if (full)
+                    RK_HIP(r, hipMemcpy2DAsync(m->d_frame + (size_t)p * kBlockRows * w * 3, block_bytes * world, from, block_bytes,
+                                               block_bytes, full, hipMemcpyDeviceToDevice, r.stream));
+                if (rest)
+                    RK_HIP(r, hipMemcpyAsync(m->d_frame + ((size_t)full * world + p) * kBlockRows * w * 3, from + (size_t)full * kBlockRows * w * 3,
+                                             (size_t)rest * w * 3 * sizeof(float), hipMemcpyDeviceToDevice, r.stream));
+            }
+            RK_HIP(r, hipEventRecord(r.ev_b, r.stream));
+            RK_HIP(r, hipStreamSynchronize(r.stream));
+            RK_HIP(r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
+        });
+        r0.worker->wait();
+        if (!r0.error.empty()) return m->fail("device %d: %s", r0.device, r0.error.c_str());
+    }
 
     // 3. framebuffer to the host if asked for
     if (out_rgb) {

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 const uint32_t pix_local = cellid >> 2, cell = cellid & 3u;
                 const uint32_t ry = pix_local / K.w;
                 const uint32_t px = pix_local - ry * K.w;
-                const uint32_t py = K.row_begin + ry;
+                const uint32_t py = K.row_begin + (ry >> K.rb_log2) * K.rb_stride + (ry & K.rb_mask);   // band or interleaved row blocks
                 const uint32_t pixel_idx = py * K.w + px;                    // GLOBAL index (:298)
                 const uint32_t p0 = mix32(pixel_idx + K.s0);
                 const uint32_t p1 = mix32(pixel_idx ^ K.s1);

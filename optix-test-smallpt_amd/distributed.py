@@ -22,15 +22,43 @@ def row_band(h, world_size, rank):
     return begin, count
 
 
+def interleaved_rows(h, block_rows, world_size, rank):
+    """Image rows of rank `rank` when the rows are dealt out round-robin in blocks of `block_rows` rows (block t belongs
+    to rank t % world_size), ascending.  Contiguous bands of a Cornell-like image differ by up to 1.34x in cost (floor and
+    spheres below, ceiling above: tools/probe_band_balance.py); interleaved blocks balance the ranks."""
+    rows = []
+    for start in range(rank * block_rows, h, world_size * block_rows):
+        rows.extend(range(start, min(start + block_rows, h)))
+    return rows
+
+
 class FrameAssembler:
     """Owns the destination memory of the exchange: on `dst` the whole (h, w, 3) framebuffer, elsewhere this rank's
-    band.  ``band`` is the tensor a rank renders into (on dst: a view of its rows inside the framebuffer);
-    ``gather()`` runs the exchange and returns the framebuffer on dst, None elsewhere."""
+    rows.  ``band`` is the tensor a rank renders into; ``gather()`` runs the exchange and returns the framebuffer on dst,
+    None elsewhere.
 
-    def __init__(self, w, h, device="cpu", group=None, dst=0, dtype=torch.float32):
-        self.w, self.h, self.group, self.dst = w, h, group, dst
+    interleave = 0: contiguous bands (row_band); on dst ``band`` is a view of its rows inside the framebuffer and the
+    other bands are received straight into their row slices.
+    interleave = B > 0: rows dealt out round-robin in blocks of B rows (interleaved_rows); every rank's packed rows are
+    received into a staging tensor on dst and scattered to their rows with one index_copy per rank."""
+
+    def __init__(self, w, h, device="cpu", group=None, dst=0, dtype=torch.float32, interleave=0):
+        self.w, self.h, self.group, self.dst, self.interleave = w, h, group, dst, int(interleave)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.interleave and self.world > 1:
+            self.rows = [interleaved_rows(h, self.interleave, self.world, r) for r in range(self.world)]
+            self.begin, self.count = None, len(self.rows[self.rank])
+            self.band = torch.empty((self.count, w, 3), dtype=dtype, device=device)
+            if self.rank == dst:
+                self.frame = torch.empty((h, w, 3), dtype=dtype, device=device)
+                self._index = [torch.tensor(r, dtype=torch.long, device=device) for r in self.rows]
+                self._staging = [self.band if r == dst else torch.empty((len(self.rows[r]), w, 3), dtype=dtype, device=device)
+                                 for r in range(self.world)]
+            else:
+                self.frame = None
+            return
+        self.interleave = 0
         self.begin, self.count = row_band(h, self.world, self.rank)
         if self.rank == dst:
             self.frame = torch.empty((h, w, 3), dtype=dtype, device=device)
@@ -45,14 +73,24 @@ class FrameAssembler:
         ops = []
         if self.rank == self.dst:
             for r in range(self.world):
-                b, c = row_band(self.h, self.world, r)
-                if r != self.dst and c:
-                    ops.append(dist.P2POp(dist.irecv, self.frame[b:b + c], r, self.group))
+                if r == self.dst:
+                    continue
+                if self.interleave:
+                    if len(self.rows[r]):
+                        ops.append(dist.P2POp(dist.irecv, self._staging[r], r, self.group))
+                else:
+                    b, c = row_band(self.h, self.world, r)
+                    if c:
+                        ops.append(dist.P2POp(dist.irecv, self.frame[b:b + c], r, self.group))
         elif self.count:
             ops.append(dist.P2POp(dist.isend, self.band, self.dst, self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if self.interleave and self.rank == self.dst:
+            for r in range(self.world):
+                if len(self.rows[r]):
+                    self.frame.index_copy_(0, self._index[r], self._staging[r])
         return self.frame
 
 

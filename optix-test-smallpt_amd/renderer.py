@@ -155,6 +155,20 @@ class Renderer:
         """'pool' (spt_pool.hip, material-sorted) or 'mega' (spt_kernel.hip) for the last launch."""
         return "pool" if self._lib.spt_last_kernel(self._h) == 1 else "mega"
 
+    def render_interleaved_device(self, out_tensor, w, h, block_rows, world, rank, samps_per_cell, seed=0,
+                                  normalise=False, camera=None, stream=None):
+        """Like render_rows_device for the rows of rank `rank` when the image is dealt out to `world` ranks round-robin in
+        blocks of `block_rows` rows (spt_render_interleaved_device); out_tensor holds those rows packed in ascending order."""
+        rows = int(self._lib.spt_interleaved_row_count(h, block_rows, world, rank))
+        if out_tensor.numel() != rows * w * 3 or not out_tensor.is_contiguous():
+            raise ValueError(f"out_tensor must be contiguous with {rows}*w*3 float32 elements")
+        if str(out_tensor.dtype) != "torch.float32" or out_tensor.device.type != "cuda":
+            raise ValueError("out_tensor must be a float32 tensor on the GPU")
+        cam = camera if camera is not None else smallpt_camera(w, h)
+        self._check(self._lib.spt_render_interleaved_device(
+            self._h, C.byref(cam), w, h, block_rows, world, rank, samps_per_cell, seed,
+            FLAG_NORMALISE if normalise else 0, C.c_void_p(out_tensor.data_ptr()), C.c_void_p(stream) if stream else None))
+
     def diag(self):
         """Phase timings / lane counters of the last launch of the instrumented build (variant bit 8)."""
         arr = (C.c_uint64 * 15)()
@@ -180,13 +194,14 @@ class MultiRenderer:
     RCCL exchange into the root device's framebuffer.  `self_exchange` routes a single device's band through RCCL too
     (rehearsal of the exchange step on a one-GPU box)."""
 
-    SELF_EXCHANGE = 1
+    SELF_EXCHANGE, CONTIGUOUS, COPY_EXCHANGE = 1, 2, 4
 
-    def __init__(self, device_ids=(0,), self_exchange=False):
+    def __init__(self, device_ids=(0,), self_exchange=False, contiguous=False, copy_exchange=False):
         self._lib = load_multi_library()
         ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
         h = C.c_void_p()
-        if self._lib.spt_multi_create(ids, len(device_ids), self.SELF_EXCHANGE if self_exchange else 0, C.byref(h)):
+        flags = (self.SELF_EXCHANGE if self_exchange else 0) | (self.CONTIGUOUS if contiguous else 0) | (self.COPY_EXCHANGE if copy_exchange else 0)
+        if self._lib.spt_multi_create(ids, len(device_ids), flags, C.byref(h)):
             raise SptError(self._lib.spt_multi_last_error(None).decode())
         self._h = h
         self.device_ids = tuple(int(d) for d in device_ids)

@@ -235,6 +235,33 @@ def test_row_bands_on_device_match_full_image(pkg, renderer):
         assert np.array_equal(np.concatenate(parts), full)
 
 
+def test_interleaved_row_blocks_on_device_match_full_image(pkg, renderer):
+    """spt_render_interleaved_device: the rows of every rank of a round-robin block partition, rendered one rank after the
+    other on this GPU and scattered to their places, give the same framebuffer as one full render (pool kernel, and the
+    megakernel through a 40-sphere scene)."""
+    import torch
+    from optix_test_smallpt_amd.distributed import interleaved_rows
+    for scene, w, h, samps, seed in ((pkg.cornell9(), 64, 50, 2, 77), (pkg.random_spheres(40, 3), 33, 37, 1, 5)):
+        renderer.set_scene(scene)
+        full, fst = renderer.render(w, h, samps, seed=seed, normalise=True)
+        for world, block in ((2, 16), (3, 4), (8, 2), (8, 16)):
+            out = np.full((h, w, 3), np.nan, dtype=np.float32)
+            bounces = 0
+            for r in range(world):
+                rows = interleaved_rows(h, block, world, r)
+                if not rows:
+                    continue
+                t = torch.empty((len(rows), w, 3), dtype=torch.float32, device="cuda:0")
+                renderer.render_interleaved_device(t, w, h, block, world, r, samps, seed=seed, normalise=True,
+                                                   stream=torch.cuda.current_stream().cuda_stream)
+                bounces += renderer.sync()["bounces"]
+                out[rows] = t.cpu().numpy()
+            assert np.array_equal(out, full) and bounces == fst["bounces"], (world, block)
+    with pytest.raises(pkg.SptError, match="power of two"):
+        n = len(interleaved_rows(8, 3, 2, 0))
+        renderer.render_interleaved_device(torch.empty((n, 8, 3), device="cuda:0"), 8, 8, 3, 2, 0, 1)
+
+
 def test_unaligned_output_pointer(pkg, renderer):
     """The store kernel has a 16-byte-aligned fast path (LDS transpose + float4 stores) and a scalar path."""
     import torch

@@ -90,6 +90,59 @@ def _worker(rank, world, port, w, h, samps, seed, outfile):
     dist.destroy_process_group()
 
 
+def test_interleaved_row_partition(pkg):
+    """Round-robin row blocks: every row belongs to exactly one rank, the C-ABI's count equals the Python partition."""
+    from optix_test_smallpt_amd.distributed import interleaved_rows
+    lib = pkg.load_library()
+    for h in (1, 15, 16, 17, 50, 768, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            for b in (1, 4, 16):
+                seen = []
+                for rank in range(world):
+                    rows = interleaved_rows(h, b, world, rank)
+                    assert rows == sorted(rows) and lib.spt_interleaved_row_count(h, b, world, rank) == len(rows)
+                    seen += rows
+                assert sorted(seen) == list(range(h))
+
+
+def _worker_interleaved(rank, world, port, w, h, block, samps, seed, outfile):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import optix_test_smallpt_amd as pkg
+    import oracle_binding as orc
+    from optix_test_smallpt_amd.distributed import FrameAssembler
+    scene = pkg.cornell9()
+    fa = FrameAssembler(w, h, interleave=block)
+    rows = fa.rows[rank]
+    for k in range(0, len(rows), block):          # the oracle stands in for the HIP renderer, one row block at a time
+        run = rows[k:k + block]
+        img, _ = orc.render(scene, w, h, samps, seed=seed, normalise=True, row_begin=run[0], row_count=len(run), threads=2)
+        fa.band[k:k + len(run)] = torch.from_numpy(img)
+    full = fa.gather()
+    if rank == 0:
+        np.save(outfile, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,block", [(24, 4), (27, 4)])      # whole blocks and a short last block
+def test_gloo_world2_interleaved_row_blocks_match_single(pkg, oracle, tmp_path, h, block):
+    """The N > 1 assembly path of bench.py: rows dealt out round-robin in blocks, packed bands sent to rank 0, scattered
+    into the framebuffer -- bit-identical to the single-process image."""
+    w, samps, seed = 20, 1, 5
+    out = str(tmp_path / "full_il.npy")
+    mp.spawn(_worker_interleaved, args=(2, _free_port(), w, h, block, samps, seed, out), nprocs=2, join=True)
+    got = np.load(out)
+    ref, _ = oracle.render(pkg.cornell9(), w, h, samps, seed=seed, normalise=True)
+    assert got.shape == (h, w, 3) and np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("h", [24, 25])      # even and uneven bands
 def test_gloo_world2_row_tiling_matches_single(pkg, oracle, tmp_path, h):
     w, samps, seed = 20, 1, 13

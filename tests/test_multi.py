@@ -73,3 +73,24 @@ def test_multi_rejects_missing_device(pkg):
     n = torch.cuda.device_count()
     with pytest.raises(pkg.SptError, match="out of range"):
         pkg.MultiRenderer((0, n + 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,contiguous", [(2, False), (3, False), (8, False), (3, True)])
+def test_several_ranks_on_one_device_assemble_the_same_image(pkg, renderer, ranks, contiguous):
+    """The whole multi-rank machinery of spt_multi_render on the one-GPU box: `ranks` host threads + contexts that share
+    device 0 (SPT_MULTI_COPY_EXCHANGE: peer copies instead of RCCL, which needs one device per rank), rows dealt out
+    round-robin in blocks of 16 (or contiguous bands), packed rows pulled to the root's staging buffer and scattered into
+    the framebuffer.  Ragged height: short last block, ranks with different row counts."""
+    w, h, samps, seed = 40, 75, 2, 3
+    sc = pkg.cornell9()
+    renderer.set_scene(sc)
+    ref, rst = renderer.render(w, h, samps, seed=seed, normalise=True)
+    with pkg.MultiRenderer((0,) * ranks, contiguous=contiguous, copy_exchange=True) as m:
+        m.set_scene(sc)
+        img, st = m.render(w, h, samps, seed=seed, normalise=True)
+        assert np.array_equal(img, ref), f"{int((img != ref).any(axis=-1).sum())} pixels differ"
+        assert st["bounces"] == rst["bounces"] and st["samples"] == rst["samples"] and st["ndev"] == ranks
+        img2, _ = m.render(w, h + 6, samps, seed=seed, normalise=True)             # buffers grow, other partition
+        ref2, _ = renderer.render(w, h + 6, samps, seed=seed, normalise=True)
+        assert np.array_equal(img2, ref2)
