@@ -787,6 +787,27 @@ int spt_selftest_math(spt_ctx* c, int op, const float* in, float* out, uint32_t 
     return 0;
 }
 
+// Exhaustive device checks of sqrt_rsq (op 0; 1 = negative control) and rcp_exact<false> (op 2; 3 = negative control) for the bit patterns [first, first + count).
+int spt_selftest_range(spt_ctx* c, int op, uint32_t first, uint32_t count, uint64_t* mismatches, uint32_t* first_bad)
+{
+    if (!c) return 1;
+    if (!mismatches || !first_bad) return c->fail("spt_selftest_range: NULL argument");
+    SPT_HIP(c, hipSetDevice(c->device));
+    unsigned long long* d_m = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_m), 16);
+    const unsigned long long init[2] = {0ull, 0xFFFFFFFFull};
+    if (e == hipSuccess) e = hipMemcpy(d_m, init, 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = spt_k_selftest_range(op, first, count, d_m, reinterpret_cast<uint32_t*>(d_m + 1), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    unsigned long long out[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(out, d_m, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d_m);
+    if (e != hipSuccess) return c->fail("spt_selftest_range: %s", hipGetErrorString(e));
+    *mismatches = out[0];
+    *first_bad = (uint32_t)out[1];
+    return 0;
+}
+
 // smallpt.cpp:52
 int spt_to_int(float x)
 {

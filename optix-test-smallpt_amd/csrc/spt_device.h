@@ -57,6 +57,25 @@ __device__ __forceinline__ float sqrt_fix_int(float x)
     const uint32_t up = ((0u - __float_as_uint(rd)) >> 31) + ((0u - __float_as_uint(ru)) >> 31);
     return __uint_as_float(sb - 1u + up);
 }
+// Correctly rounded sqrtf from v_rsq_f32 and one exact-residual correction: 1 quarter-rate + 5 full-rate instructions
+// (8.3 issue slots) against 1 + 9 + 1 half-rate (13) for sqrt_fix_int.  y ~ 1/sqrt(x); g = RN(x*y) ~ sqrt(x) to about
+// 2 ulp; d = x - g*g (one FMA, so the residual carries no rounding of g*g); result = RN(g + d*(y/2)).  Whether that last
+// rounding is the correct one for every input depends on the hardware's v_rsq_f32 table, so unlike the two forms above
+// it cannot be enumerated on the CPU: tests/test_gpu_math.py compares it on the device with sqrt_fix for EVERY binary32
+// input 2^-96 <= x < inf (1 879 048 192 values, 0 mismatches on gfx950; the uncorrected g is the test's negative control)
+// and for x = 0, -0, x < 0 and NaN (0, -0, NaN, NaN as IEEE).  x = +inf gives NaN and 0 < x < 2^-96 is not correctly
+// rounded: the API routes scenes that can produce either to the guarded build, as for sqrt_fix_int.
+// The reciprocal square root is taken of x + 2^-125 (== x for x >= 2^-96 under round-to-nearest) so that x = 0 gives
+// a finite y and g = 0 * y = 0 rather than 0 * inf.
+template <bool CORRECT = true>
+__device__ __forceinline__ float sqrt_rsq(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x + 0x1p-125f);
+    const float g = x * y;
+    if (!CORRECT) return g;
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, 0.5f * y, g);
+}
 // General form: for 0 < x < 2^-96 the residuals would underflow, so those (practically never occurring)
 // inputs take the compiler's scaled sequence.  One integer compare covers the range test.
 __device__ __forceinline__ float sqrt_exact(float x)
@@ -67,23 +86,21 @@ __device__ __forceinline__ float sqrt_exact(float x)
 }
 
 // ---- correctly rounded 1.0f / y --------------------------------------------------------------------------
-// v_rcp_f32 (1 ulp) + two FMA Newton steps give RN(1/y) for every binary32 y whose mantissa is not all
-// ones (Markstein; enumerated for all 2^23 mantissas in tools/verify_exact_math.c).  The all-ones mantissa
-// and exponents where the residual could under/overflow take the compiler's IEEE division (rare branch).
+// v_rcp_f32 + ONE FMA Newton step.  With an arbitrary 1-ulp starting value a second step (Markstein) and a special case
+// for the all-ones mantissa are needed (tools/verify_exact_math.c enumerates that model); gfx950's v_rcp_f32 is good enough
+// that one step already gives RN(1/y) for every binary32 y in 2^-100 <= y < 2^100, all-ones mantissas included -- a
+// property of the hardware table, established like sqrt_rsq by enumeration on the device: tests/test_gpu_math.py compares
+// all 1 677 721 600 inputs with the compiler's IEEE division (0 mismatches; bare v_rcp_f32 is the negative control).
+// Outside that range the residual could under/overflow: RANGE_CHECK takes the IEEE division there (rare branch);
+// RANGE_CHECK = false is used where the caller guarantees the range (lengths of unit-scale vectors / sphere radii
+// validated by the host).
 template <bool RANGE_CHECK = true>
 __device__ __forceinline__ float rcp_exact(float y)
 {
     float r = __builtin_amdgcn_rcpf(y);
-    float e = __builtin_fmaf(-y, r, 1.0f);
+    const float e = __builtin_fmaf(-y, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
-    e = __builtin_fmaf(-y, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    const uint32_t u = __float_as_uint(y);
-    // safe range: 2^-100 <= y < 2^100 (positive, normal) and mantissa != 0x7FFFFF.  RANGE_CHECK = false is used
-    // where the caller guarantees the range (lengths of unit-scale vectors / sphere radii validated by the host).
-    bool slow = (u & 0x7FFFFFu) == 0x7FFFFFu;
-    if (RANGE_CHECK) slow = slow || ((u - 0x0D800000u) >= (0x71800000u - 0x0D800000u));
-    if (__builtin_expect(slow, 0)) r = 1.0f / y;
+    if (RANGE_CHECK && __builtin_expect((__float_as_uint(y) - 0x0D800000u) >= (0x71800000u - 0x0D800000u), 0)) r = 1.0f / y;
     return r;
 }
 
@@ -92,7 +109,7 @@ template <bool GUARD = true>
 __device__ __forceinline__ f3 normalize(f3 v)
 {
     const float q = dot(v, v);
-    const float inv = GUARD ? rcp_exact<true>(sqrt_exact(q)) : rcp_exact<false>(sqrt_fix_int(q));
+    const float inv = GUARD ? rcp_exact<true>(sqrt_exact(q)) : rcp_exact<false>(sqrt_rsq(q));
     return v * inv;
 }
 

@@ -35,6 +35,16 @@ int  spt_last_kernel(spt_ctx* ctx);
  * Used by tests/test_gpu_math.py. */
 int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32_t n, uint32_t w);
 
+/* Exhaustive device checks of the two helpers whose exactness rests on the hardware's v_rsq_f32 / v_rcp_f32 tables
+ * (csrc/spt_device.h), over every binary32 bit pattern in [first, first + count): number of mismatches and the smallest
+ * offending pattern (0xFFFFFFFF if none).
+ *   op 0  sqrt_rsq (the kernels' square root) against the CPU-proven sqrt_fix
+ *   op 1  its uncorrected first estimate against the same: must mismatch (proves the comparison can fail)
+ *   op 2  rcp_exact<false> (the kernels' reciprocal) against the compiler's IEEE division 1.0f / x
+ *   op 3  bare v_rcp_f32 against the same: negative control
+ * op 10 of spt_selftest_math evaluates sqrt_rsq elementwise. */
+int  spt_selftest_range(spt_ctx* ctx, int op, uint32_t first, uint32_t count, uint64_t* mismatches, uint32_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,10 +219,10 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                 if (P.sampler == 0u) {
                     // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt fix-up is exact here
                     const float r1 = 2 * u1;
-                    const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
+                    const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
                     const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
                     const float r2 = 2 * u2;
-                    const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
+                    const float q2 = sqrt_rsq(r2 < 1 ? r2 : 2 - r2);
                     const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                     // :331-332 in double as in the reference.  a / w is evaluated as q0 = a*y, q = fma(fma(-q0,w,a), y, q0)
                     // with y = RN(1/w): the correctly rounded quotient (Markstein; checked in tools/verify_exact_math.c).
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
             uint32_t inst = 0;
             // one sphere test; branch-free (det < 0 -> NaN keys that never win)
             auto test_sphere = [&](const float4 g, uint32_t i, float b, float det) {
-                const float sd = GUARD ? sqrt_exact(det) : sqrt_fix_int(det);          // :134
+                const float sd = GUARD ? sqrt_exact(det) : sqrt_rsq(det);          // :134
                 const uint32_t key1 = __float_as_uint(b - sd) - kEpsKeyBias;           // :135
                 const uint32_t key2 = __float_as_uint(b + sd) - kEpsKeyBias;
                 const uint32_t key = key1 < key2 ? key1 : key2;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                     if (refl == 0) {                                                   // DIFF :208-215
                         const uint32_t u1bits = rng_draw_bits(p.rbase + kGolden, k1);
                         const float r2 = rng_draw(p.rbase + 2u * kGolden, k1);
-                        const float r2s = sqrt_fix_int(r2);                               // r2 in {0} U [2^-24, 1)
+                        const float r2s = sqrt_rsq(r2);                               // r2 in {0} U [2^-24, 1)
                         float sn, cs;
                         sincos2pi_bits(u1bits, sn, cs);                                 // D17, from the raw bits of u1
                         const f3 ww = nl;
@@ -400,9 +400,9 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                         const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
                         const float s2 = ay ? ww.x : ww.y;
                         const float qu = ww.z * ww.z + s2 * s2;       // dot(ur, ur) with the zero term dropped
-                        const f3 uu = ur * rcp_exact<false>(sqrt_fix_int(qu));   // qu in [0.01, 1]
+                        const f3 uu = ur * rcp_exact<false>(sqrt_rsq(qu));   // qu in [0.01, 1]
                         const f3 vv = cross(ww, uu);
-                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix_int(1 - r2)); // :212
+                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq(1 - r2)); // :212
                     } else {
                         nd = p.d - n * 2.0f * dot(n, p.d);                             // SPEC :218-223
                     }
@@ -572,6 +572,7 @@ __global__ void selftest_math(int op, const float* __restrict__ in, float* __res
     }
     case 5: { float sn, cs; sincos2pi(x, sn, cs); y = sn; break; }
     case 6: { float sn, cs; sincos2pi(x, sn, cs); y = cs; break; }
+    case 10: y = sqrt_rsq(x); break;
     case 8: { float sn, cs; sincos2pi_bits(__float_as_uint(x), sn, cs); y = sn; break; }   // x carries the raw bits
     case 9: { float sn, cs; sincos2pi_bits(__float_as_uint(x), sn, cs); y = cs; break; }
     default: y = rng_draw(__float_as_uint(x), 0x9ABCDEF0u); break;
@@ -579,7 +580,40 @@ __global__ void selftest_math(int op, const float* __restrict__ in, float* __res
     out[i] = y;
 }
 
+// Exhaustive checks of the helpers whose exactness rests on the hardware's v_rsq_f32 / v_rcp_f32 tables, over every binary32
+// bit pattern in [first, first + count): counts the mismatches and keeps the smallest offending pattern.
+// OP 0: sqrt_rsq against the CPU-proven sqrt_fix; 1: its uncorrected estimate (negative control);
+// OP 2: rcp_exact<false> against the compiler's IEEE division; 3: bare v_rcp_f32 (negative control).
+// Grid-stride; one launch covers 2^-96 .. FLT_MAX in a few milliseconds.
+template <int OP>
+__global__ __launch_bounds__(256) void selftest_range(uint32_t first, uint32_t count, unsigned long long* mismatches, uint32_t* first_bad)
+{
+    unsigned long long bad = 0;
+    uint32_t worst = 0xFFFFFFFFu;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t bits = first + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        float got, want;
+        if (OP <= 1) { got = sqrt_rsq<OP == 0>(x); want = sqrt_fix(x); }
+        else { got = OP == 2 ? rcp_exact<false>(x) : __builtin_amdgcn_rcpf(x); want = 1.0f / x; }   // the compiler's IEEE division
+        if (__float_as_uint(got) != __float_as_uint(want)) { ++bad; worst = bits < worst ? bits : worst; }
+    }
+    if (bad) { atomicAdd(mismatches, bad); atomicMin(first_bad, worst); }
+}
+
 }  // namespace spt
+
+extern "C" hipError_t spt_k_selftest_range(int op, uint32_t first, uint32_t count, unsigned long long* d_mismatches, uint32_t* d_first_bad, hipStream_t stream)
+{
+    switch (op) {
+    case 0: hipLaunchKernelGGL(spt::selftest_range<0>, dim3(256 * 32), dim3(256), 0, stream, first, count, d_mismatches, d_first_bad); break;
+    case 1: hipLaunchKernelGGL(spt::selftest_range<1>, dim3(256 * 32), dim3(256), 0, stream, first, count, d_mismatches, d_first_bad); break;
+    case 2: hipLaunchKernelGGL(spt::selftest_range<2>, dim3(256 * 32), dim3(256), 0, stream, first, count, d_mismatches, d_first_bad); break;
+    case 3: hipLaunchKernelGGL(spt::selftest_range<3>, dim3(256 * 32), dim3(256), 0, stream, first, count, d_mismatches, d_first_bad); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream)
 {

@@ -188,10 +188,10 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
             float ax, ay;
             if (K.sampler == 0u) {
                 const float r1 = 2 * u1;
-                const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
+                const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
                 const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
                 const float r2 = 2 * u2;
-                const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
+                const float q2 = sqrt_rsq(r2 < 1 ? r2 : 2 - r2);
                 const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                 const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
                 const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;

@@ -249,10 +249,10 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 float ax, ay;
                 if (K.sampler == 0u) {
                     const float r1 = 2 * u1;                                  // tent filter :327-330
-                    const float q1 = sqrt_fix_int(r1 < 1 ? r1 : 2 - r1);
+                    const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
                     const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
                     const float r2 = 2 * u2;
-                    const float q2 = sqrt_fix_int(r2 < 1 ? r2 : 2 - r2);
+                    const float q2 = sqrt_rsq(r2 < 1 ? r2 : 2 - r2);
                     const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                     // :331-332 in double like the reference; a / w as the exact Markstein sequence (tools/verify_exact_math.c)
                     const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 if (is_diff) {                                                              // DIFF :208-215
                     const uint32_t u1bits = rng_draw_bits(rbase + kGolden, k1);
                     const float r2 = rng_draw(rbase + 2u * kGolden, k1);
-                    const float r2s = sqrt_fix_int(r2);
+                    const float r2s = sqrt_rsq(r2);
                     float sn, cs;
                     sincos2pi_bits(u1bits, sn, cs);                                          // D17
                     const f3 ww = nl;
@@ -304,9 +304,9 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                     const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
                     const float s2 = ay ? ww.x : ww.y;
                     const float qu = ww.z * ww.z + s2 * s2;
-                    const f3 uu = ur * rcp_exact<false>(sqrt_fix_int(qu));
+                    const f3 uu = ur * rcp_exact<false>(sqrt_rsq(qu));
                     const f3 vv = cross(ww, uu);
-                    d = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_fix_int(1 - r2));   // :212
+                    d = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq(1 - r2));   // :212
                 } else {
                     d = din - n * 2.0f * dot(n, din);                                       // SPEC :218-223
                 }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 const f3 op = mk(g.x - ro.x, g.y - ro.y, g.z - ro.z);                       // :132
                 const float bb = dot(op, rd);                                               // :133
                 const float det = bb * bb - dot(op, op) + g.w;                              // :133
-                const float sd = sqrt_fix_int(det);                                         // :134
+                const float sd = sqrt_rsq(det);                                         // :134
                 const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;                  // :135
                 const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;
                 key = key1 < key2 ? key1 : key2;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                         const f3 op = mk(g[j].x - o.x, g[j].y - o.y, g[j].z - o.z);         // :132
                         const float bb = dot(op, d);                                        // :133
                         const float det = bb * bb - dot(op, op) + g[j].w;                   // :133 (g.w = r*r)
-                        const float sd = sqrt_fix_int(det);                                 // :134
+                        const float sd = sqrt_rsq(det);                                 // :134
                         const uint32_t key1 = __float_as_uint(bb - sd) - kEpsBias;          // :135
                         const uint32_t key2 = __float_as_uint(bb + sd) - kEpsBias;
                         nk[base + j + 1] = umin3(nk[base + j], key1, key2);

@@ -26,7 +26,7 @@ def test_sqrt_helpers_are_correctly_rounded(renderer):
     x = _inputs()
     ref = np.sqrt(x)
     big = x >= f32(2.0**-96)
-    for op, name in ((0, "sqrt_fix"), (1, "sqrt_fix_int")):
+    for op, name in ((0, "sqrt_fix"), (1, "sqrt_fix_int"), (10, "sqrt_rsq")):
         y = renderer.selftest_math(op, x)
         ok = (y == ref) | ~(big | (x == 0))          # un-guarded forms are specified for x = 0 or x >= 2^-96
         assert ok.all(), (name, x[~ok][:5], y[~ok][:5], ref[~ok][:5])
@@ -34,11 +34,40 @@ def test_sqrt_helpers_are_correctly_rounded(renderer):
     assert (y == ref).all(), (x[y != ref][:5], y[y != ref][:5])
     # special values: +0 stays +0, inf stays inf, negatives and NaN give NaN
     sp = np.array([0.0, np.inf, -1.0, np.nan], dtype=np.float32)
-    for op in (0, 1, 2):
+    for op in (0, 1, 2, 10):
         y = renderer.selftest_math(op, sp)
         assert y[0] == 0 and not np.signbit(y[0]) and np.isnan(y[2]) and np.isnan(y[3])
-        if op != 1:       # the integer fix-up is specified for finite arguments only (the API selects the
+        if op not in (1, 10):       # the integer fix-up is specified for finite arguments only (the API selects the
             assert y[1] == np.inf   # guarded kernel build for scenes whose coordinates could overflow)
+
+
+def test_sqrt_rsq_exhaustive(renderer):
+    """The kernels' square root (v_rsq_f32 + one exact-residual FMA correction, csrc/spt_device.h sqrt_rsq) depends on the
+    hardware's reciprocal-square-root table, so its correct rounding is established by enumeration ON THE DEVICE: every
+    binary32 value in its specified range 2^-96 <= x < inf (1 879 048 192 inputs) must equal the CPU-proven sqrt_fix bit
+    for bit.  The uncorrected estimate run through the same comparison is the negative control."""
+    lo, hi = (127 - 96) << 23, 0x7F800000
+    m, first_bad = C.c_uint64(), C.c_uint32()
+    lib, h = renderer._lib, renderer._h
+    assert lib.spt_selftest_range(h, 0, lo, hi - lo, C.byref(m), C.byref(first_bad)) == 0
+    assert m.value == 0 and first_bad.value == 0xFFFFFFFF, (m.value, hex(first_bad.value))
+    assert lib.spt_selftest_range(h, 1, lo, hi - lo, C.byref(m), C.byref(first_bad)) == 0
+    assert m.value > 1_000_000 and lo <= first_bad.value < hi, (m.value, hex(first_bad.value))
+    x = np.array([0.0, -0.0], dtype=np.float32)
+    y = renderer.selftest_math(10, x)
+    assert y[0] == 0 and not np.signbit(y[0]) and y[1] == 0 and np.signbit(y[1])
+
+
+def test_rcp_exact_exhaustive(renderer):
+    """rcp_exact<false> (v_rcp_f32 + one FMA Newton step) against the compiler's IEEE division for every binary32 value in
+    2^-100 <= y < 2^100: as for sqrt_rsq the property belongs to the hardware table and is enumerated on the device."""
+    lo, hi = (127 - 100) << 23, (127 + 100) << 23
+    m, first_bad = C.c_uint64(), C.c_uint32()
+    lib, h = renderer._lib, renderer._h
+    assert lib.spt_selftest_range(h, 2, lo, hi - lo, C.byref(m), C.byref(first_bad)) == 0
+    assert m.value == 0 and first_bad.value == 0xFFFFFFFF, (m.value, hex(first_bad.value))
+    assert lib.spt_selftest_range(h, 3, lo, hi - lo, C.byref(m), C.byref(first_bad)) == 0
+    assert m.value > 1_000_000 and lo <= first_bad.value < hi, (m.value, hex(first_bad.value))
 
 
 def test_rcp_exact_is_correctly_rounded(renderer):

@@ -1,7 +1,9 @@
 /* verify_exact_math.c -- exhaustive / randomized CPU proof-by-enumeration that the cheap GPU sequences
  * used in optix-test-smallpt_amd/csrc/spt_device.h return the correctly rounded IEEE result:
  *   (1) sqrt fix-up:   s0 within +-1 ulp of sqrt(x)  ->  RN(sqrt(x))         (all 2^24 mantissas of [1,4))
- *   (2) reciprocal:    r0 within +-1 ulp of 1/y, two FMA Newton steps -> RN(1/y)  (all 2^23 mantissas)
+ *   (2) reciprocal:    r0 within +-1 ulp of 1/y, two FMA Newton steps -> RN(1/y)  (all 2^23 mantissas; one exception,
+ *                      the all-ones mantissa.  This is the hardware-independent MODEL; the kernels' rcp_exact uses one step
+ *                      on gfx950's actual v_rcp_f32 and is enumerated on the device, tests/test_gpu_math.py)
  *   (3) double a/w via y=RN(1/w): q0=a*y; r=fma(-q0,w,a); q=fma(r,y,q0) == a/w   (w in [1,16384], random a)
  * Build: gcc -O2 -mfma -ffp-contract=off tools/verify_exact_math.c -lm -o /tmp/verify_exact_math
  * Exit code 0 = every case matched.  The list of reciprocal exceptions (if any) is printed. */
