@@ -67,21 +67,23 @@ __device__ __forceinline__ float sqrt_fix_int(float x)
 // rounded: the API routes scenes that can produce either to the guarded build, as for sqrt_fix_int.
 // The reciprocal square root is taken of x + 2^-125 (== x for x >= 2^-96 under round-to-nearest) so that x = 0 gives
 // a finite y and g = 0 * y = 0 rather than 0 * inf.
-template <bool CORRECT = true>
+// NONZERO: the caller guarantees x != 0 (x >= 2^-96, negative or NaN), which saves the addition.
+template <bool CORRECT = true, bool NONZERO = false>
 __device__ __forceinline__ float sqrt_rsq(float x)
 {
-    const float y = __builtin_amdgcn_rsqf(x + 0x1p-125f);
+    const float y = __builtin_amdgcn_rsqf(NONZERO ? x : x + 0x1p-125f);
     const float g = x * y;
     if (!CORRECT) return g;
     const float d = __builtin_fmaf(-g, g, x);
     return __builtin_fmaf(d, 0.5f * y, g);
 }
-// General form: for 0 < x < 2^-96 the residuals would underflow, so those (practically never occurring)
-// inputs take the compiler's scaled sequence.  One integer compare covers the range test.
+// General form: for 0 < x < 2^-96 the residual would underflow and x = +inf gives inf * 0, so those (practically never
+// occurring) inputs take the compiler's scaled sequence.
 __device__ __forceinline__ float sqrt_exact(float x)
 {
-    float s = sqrt_fix(x);
-    if (__builtin_expect((__float_as_uint(x) - 1u) < (0x0F800000u - 1u), 0)) s = __builtin_sqrtf(x);
+    float s = sqrt_rsq(x);
+    const uint32_t u = __float_as_uint(x);
+    if (__builtin_expect((u - 1u) < (0x0F800000u - 1u) || u == 0x7F800000u, 0)) s = __builtin_sqrtf(x);
     return s;
 }
 
@@ -109,7 +111,7 @@ template <bool GUARD = true>
 __device__ __forceinline__ f3 normalize(f3 v)
 {
     const float q = dot(v, v);
-    const float inv = GUARD ? rcp_exact<true>(sqrt_exact(q)) : rcp_exact<false>(sqrt_rsq(q));
+    const float inv = GUARD ? rcp_exact<true>(sqrt_exact(q)) : rcp_exact<false>(sqrt_rsq<true, true>(q));
     return v * inv;
 }
 

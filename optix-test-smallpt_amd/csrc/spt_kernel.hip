@@ -400,9 +400,9 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                         const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
                         const float s2 = ay ? ww.x : ww.y;
                         const float qu = ww.z * ww.z + s2 * s2;       // dot(ur, ur) with the zero term dropped
-                        const f3 uu = ur * rcp_exact<false>(sqrt_rsq(qu));   // qu in [0.01, 1]
+                        const f3 uu = ur * rcp_exact<false>(sqrt_rsq<true, true>(qu));   // qu in [0.01, 1]
                         const f3 vv = cross(ww, uu);
-                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq(1 - r2)); // :212
+                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq<true, true>(1 - r2)); // :212
                     } else {
                         nd = p.d - n * 2.0f * dot(n, p.d);                             // SPEC :218-223
                     }

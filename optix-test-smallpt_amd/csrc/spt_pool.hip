@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     uint32_t it_total = 0;
     bool timed_out = false;
-    unsigned long long t_dry = 0;                                // when this wave found the task queue empty
+    uint32_t dry_lo = 0, dry_hi = 0;                             // when this wave found the task queue empty: written once, read once,
+                                                                 // so parked in vector registers rather than in scarce scalar ones
 
     for (;;) {
         // ---- choose the class of this batch: a full batch of the rarest class first, else the longest list ----
@@ -209,7 +210,11 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                         uint32_t nb = 0;
                         if ((int)lane == leader) nb = atomicAdd(K.queue, 64u);
                         base_new = uni(__shfl(nb, leader));
-                        if (base_new >= K.ntasks) { queue_empty = true; t_dry = __builtin_amdgcn_s_memtime(); }
+                        if (base_new >= K.ntasks) {
+                            queue_empty = true;
+                            const unsigned long long t = __builtin_amdgcn_s_memtime();
+                            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(dry_lo), "=v"(dry_hi) : "s"((uint32_t)t), "s"((uint32_t)(t >> 32)));
+                        }
                     } else {
                         base_new = K.ntasks;                     // nothing left: ids >= ntasks mean "no task"
                     }
@@ -304,9 +309,9 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                     const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
                     const float s2 = ay ? ww.x : ww.y;
                     const float qu = ww.z * ww.z + s2 * s2;
-                    const f3 uu = ur * rcp_exact<false>(sqrt_rsq(qu));
+                    const f3 uu = ur * rcp_exact<false>(sqrt_rsq<true, true>(qu));
                     const f3 vv = cross(ww, uu);
-                    d = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq(1 - r2));   // :212
+                    d = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq<true, true>(1 - r2));   // :212
                 } else {
                     d = din - n * 2.0f * dot(n, din);                                       // SPEC :218-223
                 }
@@ -513,6 +518,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         // longest wave, longest and summed time a wave kept running after it found the task queue empty
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         atomicMax(&K.counters[12], t_end - t_start);
+        const unsigned long long t_dry = ((unsigned long long)uni(dry_hi) << 32) | uni(dry_lo);
         if (t_dry) { atomicMax(&K.counters[13], t_end - t_dry); atomicAdd(&K.counters[14], t_end - t_dry); }
         atomicAdd(&K.counters[15], t_end - t_start);
     }
