@@ -231,7 +231,7 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
     c->n = n;
     c->mesh_scene = false;
-    // The un-guarded sqrt fix-up in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
+    // The un-guarded square root (sqrt_rsq) in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
     // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
     c->needs_guard = false;
     for (uint32_t i = 0; i < n; ++i) {
@@ -768,7 +768,7 @@ int spt_set_watchdog(spt_ctx* c, double seconds)
 
 int spt_last_kernel(spt_ctx* c) { return c ? (c->last_was_pool ? 1 : 0) : -1; }
 
-// Numerics self-test: runs device helper `op` (0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact,
+// Numerics self-test: runs device helper `op` (0 sqrt_fix, 2 sqrt_exact, 3 rcp_exact, 10 sqrt_rsq,
 // 4 double division by w, 5/6 sin/cos(2*pi*x), 7 rng_draw(bits(x))) over n host floats.
 int spt_selftest_math(spt_ctx* c, int op, const float* in, float* out, uint32_t n, uint32_t w)
 {

@@ -41,30 +41,14 @@ __device__ __forceinline__ float sqrt_fix(float x)
     s = ru > 0.0f ? su : s;
     return s;
 }
-// Same fix-up with the two selects done in integer arithmetic: s-1ulp + [rd > 0] + [ru > 0], where
-// [v > 0] = (0 - bits(v)) >> 31 for any v that is not -0 (rd, ru are exact-zero or non-zero residuals of
-// opposite-signed addends, so -0 cannot occur; x itself is never -0 at the call site).  Full-rate integer ops
-// instead of v_cmp/v_cndmask pairs.  Specified for x = 0, 2^-96 <= x < inf, x < 0 and NaN (x = +inf would give
-// FLT_MAX: the API routes scenes whose coordinates could overflow to the guarded build).
-__device__ __forceinline__ float sqrt_fix_int(float x)
-{
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const uint32_t sb = __float_as_uint(s);
-    const float sd = __uint_as_float(sb - 1u);
-    const float su = __uint_as_float(sb + 1u);
-    const float rd = __builtin_fmaf(-sd, s, x);
-    const float ru = __builtin_fmaf(-su, s, x);
-    const uint32_t up = ((0u - __float_as_uint(rd)) >> 31) + ((0u - __float_as_uint(ru)) >> 31);
-    return __uint_as_float(sb - 1u + up);
-}
 // Correctly rounded sqrtf from v_rsq_f32 and one exact-residual correction: 1 quarter-rate + 5 full-rate instructions
-// (8.3 issue slots) against 1 + 9 + 1 half-rate (13) for sqrt_fix_int.  y ~ 1/sqrt(x); g = RN(x*y) ~ sqrt(x) to about
+// (8.3 issue slots) against 13 for v_sqrt_f32 + fix-up.  y ~ 1/sqrt(x); g = RN(x*y) ~ sqrt(x) to about
 // 2 ulp; d = x - g*g (one FMA, so the residual carries no rounding of g*g); result = RN(g + d*(y/2)).  Whether that last
 // rounding is the correct one for every input depends on the hardware's v_rsq_f32 table, so unlike the two forms above
 // it cannot be enumerated on the CPU: tests/test_gpu_math.py compares it on the device with sqrt_fix for EVERY binary32
 // input 2^-96 <= x < inf (1 879 048 192 values, 0 mismatches on gfx950; the uncorrected g is the test's negative control)
 // and for x = 0, -0, x < 0 and NaN (0, -0, NaN, NaN as IEEE).  x = +inf gives NaN and 0 < x < 2^-96 is not correctly
-// rounded: the API routes scenes that can produce either to the guarded build, as for sqrt_fix_int.
+// rounded: the API routes scenes that can produce either to the guarded build (sqrt_exact).
 // The reciprocal square root is taken of x + 2^-125 (== x for x >= 2^-96 under round-to-nearest) so that x = 0 gives
 // a finite y and g = 0 * y = 0 rather than 0 * inf.
 // NONZERO: the caller guarantees x != 0 (x >= 2^-96, negative or NaN), which saves the addition.

@@ -30,7 +30,7 @@ int  spt_set_watchdog(spt_ctx* ctx, double seconds);
 int  spt_last_kernel(spt_ctx* ctx);
 
 /* Numerics self-test of the kernel's exact-math helpers (host arrays in/out, n elements):
- * op 0 sqrt_fix, 1 sqrt_fix_int, 2 sqrt_exact, 3 rcp_exact, 4 (float)((double)x / w) by the FMA sequence,
+ * op 0 sqrt_fix, 2 sqrt_exact, 3 rcp_exact, 10 sqrt_rsq, 4 (float)((double)x / w) by the FMA sequence,
  * 5/6 sin/cos(2*pi*x) (D17), 7 rng_draw keyed by bits(x), 8/9 sin/cos from the raw draw bits carried in x.
  * Used by tests/test_gpu_math.py. */
 int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32_t n, uint32_t w);

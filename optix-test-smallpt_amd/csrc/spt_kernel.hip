@@ -217,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                 const uint32_t sx = cell & 1u, sy = cell >> 1;
                 float ax, ay;
                 if (P.sampler == 0u) {
-                    // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt fix-up is exact here
+                    // tent filter :327-330; r in {0} U [2^-23, 2): the un-guarded sqrt_rsq is exact here
                     const float r1 = 2 * u1;
                     const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
                     const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
@@ -561,7 +561,6 @@ __global__ void selftest_math(int op, const float* __restrict__ in, float* __res
     float y;
     switch (op) {
     case 0: y = sqrt_fix(x); break;
-    case 1: y = sqrt_fix_int(x); break;
     case 2: y = sqrt_exact(x); break;
     case 3: y = rcp_exact(x); break;
     case 4: {   // double division a / w by the Markstein sequence, a = (double)x

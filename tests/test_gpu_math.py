@@ -26,7 +26,7 @@ def test_sqrt_helpers_are_correctly_rounded(renderer):
     x = _inputs()
     ref = np.sqrt(x)
     big = x >= f32(2.0**-96)
-    for op, name in ((0, "sqrt_fix"), (1, "sqrt_fix_int"), (10, "sqrt_rsq")):
+    for op, name in ((0, "sqrt_fix"), (10, "sqrt_rsq")):
         y = renderer.selftest_math(op, x)
         ok = (y == ref) | ~(big | (x == 0))          # un-guarded forms are specified for x = 0 or x >= 2^-96
         assert ok.all(), (name, x[~ok][:5], y[~ok][:5], ref[~ok][:5])
@@ -34,10 +34,10 @@ def test_sqrt_helpers_are_correctly_rounded(renderer):
     assert (y == ref).all(), (x[y != ref][:5], y[y != ref][:5])
     # special values: +0 stays +0, inf stays inf, negatives and NaN give NaN
     sp = np.array([0.0, np.inf, -1.0, np.nan], dtype=np.float32)
-    for op in (0, 1, 2, 10):
+    for op in (0, 2, 10):
         y = renderer.selftest_math(op, sp)
         assert y[0] == 0 and not np.signbit(y[0]) and np.isnan(y[2]) and np.isnan(y[3])
-        if op not in (1, 10):       # the integer fix-up is specified for finite arguments only (the API selects the
+        if op != 10:            # the rsq form is specified for finite arguments only (the API selects the
             assert y[1] == np.inf   # guarded kernel build for scenes whose coordinates could overflow)
 
 
