@@ -56,7 +56,7 @@ struct spt_ctx {
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
     float* d_frame = nullptr;
     uint32_t prog_w = 0, prog_h = 0;
-    unsigned long long pool_stats[14] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
+    unsigned long long pool_stats[15] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
     size_t cells_cap = 0;          // in float4

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     bool queue_empty = false;
     unsigned long long nbounce = 0;                              // closest-hit queries of this wave
     uint32_t nkill = 0;                                          // per lane
+    uint32_t nrec = 0;                                           // per lane: pending-child records written
     uint32_t itG = 0, itD = 0, itR = 0;                          // batches per class (utilisation report)
     unsigned long long lnG = 0, lnD = 0, lnR = 0;                // lanes per class
     uint32_t itTail = 0, itFull = 0;                             // batches after the task queue ran dry / full batches
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                             rec[2] = make_float4(tw.x, tw.y, tw.z, __uint_as_float(k1));
                             rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);              // completes the line: no partial-line write
                             ++sp;
+                            ++nrec;
                         }
                         nf = f * Re;
                     } else {
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     }
 
     // stats: one atomic per wave
-    unsigned long long nk = nkill;
-    for (int off = 32; off > 0; off >>= 1) nk += __shfl_down(nk, off);
+    unsigned long long nk = nkill, nr = nrec;
+    for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off); nr += __shfl_down(nr, off); }
     if (lane == 0) {
         atomicAdd(&K.counters[0], nbounce);
         if (nk) atomicAdd(&K.counters[1], nk);
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         const unsigned long long t_dry = ((unsigned long long)uni(dry_hi) << 32) | uni(dry_lo);
         if (t_dry) { atomicMax(&K.counters[13], t_end - t_dry); atomicAdd(&K.counters[14], t_end - t_dry); }
         atomicAdd(&K.counters[15], t_end - t_start);
+        atomicAdd(&K.counters[16], nr);                           // pending-child records written (64 B out, 64 B back in each)
     }
 }
 
