@@ -121,6 +121,26 @@ typedef struct spt_hit { float dist; uint32_t instId; uint32_t triId; float x[3]
  * triangle arithmetic (triIntersect scene.cpp:52-70, intersect :95-116, makeHit :73-93; hit.n is the interpolated,
  * un-normalised vertex normal).  spt_set_scene switches back to spheres. */
 int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
+
+/* How the closest hit of a mesh scene is found.
+ *   SPT_ACCEL_EXHAUSTIVE (default): every triangle of every instance is tested, as CPUIntersector::intersect does
+ *     (smallpt.cpp:443-458 over scene.cpp:95-116).  Bit-identical to the reference's loops on every ray.
+ *   SPT_ACCEL_BVH: the role of the OptiX Prime model/query of the reference's GPU intersector (smallpt.cpp:475-603):
+ *     a bounding-volume hierarchy built over the triangles when the mode is selected / the meshes are set.  The visited
+ *     triangles go through the same triIntersect arithmetic and the same selection (smallest dist > 0, lowest
+ *     (instance, triangle) among equal dist), so the result is the exhaustive one whenever the winning triangle's padded
+ *     box is crossed by the ray within the current nearest distance -- every hit whose ray passes within rounding
+ *     distance of its triangle.  triIntersect has no determinant cut-off (scene.cpp:62): when dot(rd, cross(e1, e2)) is
+ *     zero to rounding -- a ray lying in a triangle's plane, or a zero-area triangle such as the needles makeSphereTriMesh
+ *     puts at the poles, met exactly at a vertex -- it reports a "hit" whose distance is rounding noise; those the
+ *     hierarchy may replace by the next hit.  tests/test_meshes.py compares both modes on > 400 000 rays (random, through
+ *     vertices / edge midpoints / centroids, along edges, in-plane with tilts 0 .. 1e-2, axis-parallel, origins on the
+ *     surface): identical except for such zero-determinant reports, which it checks to be the only differences; rendered
+ *     images (camera rays never meet the condition exactly) are identical to the exhaustive kernel's and the oracle's.
+ * Applies to spt_trace_rays and to spt_render* of a mesh scene; may be changed at any time. */
+#define SPT_ACCEL_EXHAUSTIVE 0
+#define SPT_ACCEL_BVH        1
+int  spt_set_mesh_accel(spt_ctx* ctx, int accel);
 /* Vector<Hit> Intersector::traceRays(const PathContrib*, size_t) (smallpt.cpp:460-470, :553-587): closest hit of n rays
  * against the current mesh scene; host buffers in and out like the reference's RTP_BUFFER_TYPE_HOST queries (:571-575). */
 int  spt_trace_rays(spt_ctx* ctx, const spt_ray* rays, uint64_t n, spt_hit* hits);

@@ -2,6 +2,7 @@
 // Host-side only: scene upload, launch geometry, HIP-event timing, statistics, image output.
 #include "../../include/smallpt_mi355x.h"
 #include "spt_internal.h"
+#include "spt_bvh.h"
 #include "spt_kernel.h"
 
 #include <chrono>
@@ -10,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -52,6 +54,11 @@ struct spt_ctx {
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
     float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
+    std::vector<float4> h_tris;      // host copy of the triangle records: the hierarchy is built from it on demand
+    int accel = SPT_ACCEL_EXHAUSTIVE;
+    bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
+    float4* d_bvh_nodes = nullptr; float4* d_bvh_tris = nullptr; uint32_t* d_bvh_index = nullptr;
+    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     uint32_t ntris = 0, ninst = 0;
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
     float* d_frame = nullptr;
@@ -159,6 +166,9 @@ void spt_destroy(spt_ctx* c)
     if (c->d_frame) (void)hipFree(c->d_frame);
     if (c->d_tris) (void)hipFree(c->d_tris);
     if (c->d_tri_index) (void)hipFree(c->d_tri_index);
+    if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
+    if (c->d_bvh_tris) (void)hipFree(c->d_bvh_tris);
+    if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
     if (c->d_verts) (void)hipFree(c->d_verts);
     if (c->d_inst_first) (void)hipFree(c->d_inst_first);
     if (c->d_mesh_mats) (void)hipFree(c->d_mesh_mats);
@@ -299,6 +309,7 @@ uint32_t spt_make_sphere_trimesh(const float origin[3], float radius, uint32_t s
 }
 
 static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
+static int build_accel(spt_ctx* c);
 
 int spt_set_meshes(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials)
 {
@@ -365,7 +376,78 @@ static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, c
     SPT_HIP(c, upload(c->d_mesh_mats, mats.data(), mats.size() * sizeof(float4)));
     c->ntris = (uint32_t)ntris; c->ninst = nmesh;
     c->mesh_scene = true;
+    tris.resize(3 * (size_t)ntris);
+    c->h_tris.swap(tris);
+    c->bvh_ready = false;
+    return c->accel == SPT_ACCEL_BVH ? build_accel(c) : 0;
+}
+
+// Builds and uploads the hierarchy of the current mesh scene (spt_bvh.h); the caller holds the C-boundary try block.
+static int build_accel(spt_ctx* c)
+{
+    spt::Bvh bvh;
+    spt::build_bvh(c->h_tris.data(), c->ntris, bvh);
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    auto upload = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
+        if (dptr) (void)hipFree(dptr);
+        dptr = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dptr), bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    SPT_HIP(c, upload(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_bvh_tris, bvh.tris.data(), bvh.tris.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_bvh_index, bvh.index.data(), bvh.index.size() * sizeof(uint32_t)));
+    c->bvh_nodes = (uint32_t)(bvh.nodes.size() / 4); c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.leaves;
+    c->bvh_ready = true;
     return 0;
+}
+
+int spt_set_mesh_accel(spt_ctx* c, int accel)
+{
+    if (!c) return 1;
+    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH) return c->fail("spt_set_mesh_accel: unknown mode %d", accel);
+    c->accel = accel;
+    if (accel != SPT_ACCEL_BVH || !c->mesh_scene || c->bvh_ready) return 0;
+    try {
+        return build_accel(c);
+    } catch (const std::exception& e) {
+        return c->fail("spt_set_mesh_accel: %s", e.what());
+    }
+}
+
+// Host-only self-test of the builder (no device call): builds the hierarchy over the meshes' triangles and validates it.
+// out4 = {nodes, leaves, depth, triangles}.
+int spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, char* why, uint32_t why_len)
+{
+    try {
+        std::vector<float4> recs;
+        for (uint32_t i = 0; i < nmesh; ++i) {
+            const spt_mesh& m = meshes[i];
+            for (uint32_t k = 0; k < m.ntris; ++k) {
+                const uint32_t i1 = m.indices[3 * k], i2 = m.indices[3 * k + 1], i3 = m.indices[3 * k + 2];
+                if (i1 >= m.nverts || i2 >= m.nverts || i3 >= m.nverts) throw std::runtime_error("index out of range");
+                const HostF3 v0 = hld(m.positions + 3 * i1), v1 = hld(m.positions + 3 * i2), v2 = hld(m.positions + 3 * i3);
+                const HostF3 e1 = hsub(v1, v0), e2 = hsub(v2, v0);
+                const HostF3 n = hcross(e1, e2);
+                recs.push_back(make_float4(v0.x, v0.y, v0.z, n.x));
+                recs.push_back(make_float4(e1.x, e1.y, e1.z, n.y));
+                recs.push_back(make_float4(e2.x, e2.y, e2.z, n.z));
+            }
+        }
+        const uint32_t ntris = (uint32_t)(recs.size() / 3);
+        spt::Bvh bvh;
+        spt::build_bvh(recs.data(), ntris, bvh);
+        std::string reason;
+        const bool ok = spt::validate_bvh(recs.data(), ntris, bvh, reason);
+        if (out4) { out4[0] = (uint32_t)(bvh.nodes.size() / 4); out4[1] = bvh.leaves; out4[2] = bvh.depth; out4[3] = ntris; }
+        if (why && why_len) std::snprintf(why, why_len, "%s", reason.c_str());
+        return ok ? 0 : 2;
+    } catch (const std::exception& e) {
+        if (why && why_len) std::snprintf(why, why_len, "%s", e.what());
+        return 1;
+    }
 }
 
 static spt::MParams mesh_params(const spt_ctx* c)
@@ -373,6 +455,7 @@ static spt::MParams mesh_params(const spt_ctx* c)
     spt::MParams M{};
     M.tris = c->d_tris; M.tri_index = c->d_tri_index; M.verts = c->d_verts; M.inst_first_tri = c->d_inst_first; M.mats = c->d_mesh_mats;
     M.ntris = c->ntris; M.ninst = c->ninst;
+    if (c->accel == SPT_ACCEL_BVH && c->bvh_ready) { M.bvh_nodes = c->d_bvh_nodes; M.bvh_tris = c->d_bvh_tris; M.bvh_index = c->d_bvh_index; }
     return M;
 }
 

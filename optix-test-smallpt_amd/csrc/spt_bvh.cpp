@@ -1,0 +1,248 @@
+// spt_bvh.cpp -- binned-SAH builder of the optional triangle hierarchy (see spt_bvh.h for the layout and the contract).
+#include "spt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+namespace spt {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void clear() { for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -std::numeric_limits<float>::infinity(); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); } }
+    double half_area() const
+    {
+        const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+        return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx;
+    }
+};
+
+inline float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -std::numeric_limits<float>::infinity()) : f; }
+inline float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, std::numeric_limits<float>::infinity()) : f; }
+
+// Padded box of one triangle record: the vertices are v0, v0 + e1, v0 + e2 (e1, e2 carry one rounding of the reference's
+// v1 - v0, v2 - v0, far inside the padding).
+Box padded_box(const float4* r)
+{
+    const double v[3][3] = {{r[0].x, r[0].y, r[0].z},
+                            {(double)r[0].x + r[1].x, (double)r[0].y + r[1].y, (double)r[0].z + r[1].z},
+                            {(double)r[0].x + r[2].x, (double)r[0].y + r[2].y, (double)r[0].z + r[2].z}};
+    double edge2 = 0.0, big = 0.0;
+    for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 3; ++c)
+            if (!std::isfinite(v[k][c])) throw std::runtime_error("spt_set_mesh_accel: a triangle has non-finite vertices");
+    for (int k = 0; k < 3; ++k) {
+        const double* a = v[k];
+        const double* b = v[(k + 1) % 3];
+        edge2 = std::max(edge2, (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+        for (int c = 0; c < 3; ++c) big = std::max(big, std::fabs(a[c]));
+    }
+    if (!std::isfinite(edge2)) throw std::runtime_error("spt_set_mesh_accel: a triangle's extent overflows");
+    const double pad = 0.25 * std::sqrt(edge2) + 1e-4 * big + 1e-30;
+    Box b;
+    for (int c = 0; c < 3; ++c) {
+        b.mn[c] = round_down(std::min({v[0][c], v[1][c], v[2][c]}) - pad);
+        b.mx[c] = round_up(std::max({v[0][c], v[1][c], v[2][c]}) + pad);
+    }
+    return b;
+}
+
+// internal levels a subtree of `count` triangles needs when split at the median: leaf references end up that much deeper
+inline uint32_t levels_needed(uint32_t count)
+{
+    uint32_t leaves = (count + kBvhLeafTris - 1) / kBvhLeafTris, l = 0;
+    while ((1u << l) < leaves) ++l;
+    return l;
+}
+
+struct Builder {
+    const float4* recs;
+    std::vector<Box> box;            // per global triangle
+    std::vector<float> cen;          // 3 per global triangle
+    std::vector<uint32_t> order;     // permutation being partitioned
+    Bvh* out;
+
+    int32_t leaf_ref(uint32_t lo, uint32_t hi)
+    {
+        const uint32_t first = (uint32_t)out->index.size();
+        std::sort(order.begin() + lo, order.begin() + hi);               // ascending global index inside a leaf (tidy; ties are broken by index anyway)
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t g = order[i];
+            out->index.push_back(g);
+            out->tris.push_back(recs[3 * (size_t)g]); out->tris.push_back(recs[3 * (size_t)g + 1]); out->tris.push_back(recs[3 * (size_t)g + 2]);
+        }
+        ++out->leaves;
+        return ~(int32_t)((first << 3) | (hi - lo));
+    }
+
+    Box range_box(uint32_t lo, uint32_t hi) const
+    {
+        Box b; b.clear();
+        for (uint32_t i = lo; i < hi; ++i) b.grow(box[order[i]]);
+        return b;
+    }
+
+    // returns the split position in (lo, hi); children must fit into `levels_left` further internal levels each
+    uint32_t split(uint32_t lo, uint32_t hi, uint32_t levels_left)
+    {
+        const uint32_t n = hi - lo;
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { const float c = cen[3 * (size_t)order[i] + a]; cmn[a] = std::min(cmn[a], c); cmx[a] = std::max(cmx[a], c); }
+        constexpr int kBins = 16;
+        double best = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = (double)cmx[a] - cmn[a];
+            if (!(ext > 0)) continue;
+            Box bb[kBins]; uint32_t cnt[kBins] = {};
+            for (auto& b : bb) b.clear();
+            const double scale = kBins / ext;
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t g = order[i];
+                const int k = std::min(kBins - 1, (int)(((double)cen[3 * (size_t)g + a] - cmn[a]) * scale));
+                bb[k].grow(box[g]); ++cnt[k];
+            }
+            Box acc; acc.clear();
+            double right_area[kBins]; uint32_t right_cnt[kBins];
+            uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+            acc.clear(); c = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                acc.grow(bb[k]); c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                const double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+                if (cost < best) { best = cost; best_axis = a; best_bin = k; }
+            }
+        }
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double scale = kBins / ((double)cmx[a] - cmn[a]);
+            auto mid = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t g) {
+                return std::min(kBins - 1, (int)(((double)cen[3 * (size_t)g + a] - cmn[a]) * scale)) <= best_bin;
+            });
+            const uint32_t m = (uint32_t)(mid - order.begin());
+            if (m > lo && m < hi && levels_needed(m - lo) <= levels_left && levels_needed(hi - m) <= levels_left) return m;
+        }
+        // median along the widest centroid axis (or by index when all centroids coincide): depth stays logarithmic
+        int a = 0;
+        for (int k = 1; k < 3; ++k) if (cmx[k] - cmn[k] > cmx[a] - cmn[a]) a = k;
+        const uint32_t m = lo + (n + 1) / 2;
+        std::nth_element(order.begin() + lo, order.begin() + m, order.begin() + hi, [&](uint32_t x, uint32_t y) {
+            const float cx = cen[3 * (size_t)x + a], cy = cen[3 * (size_t)y + a];
+            return cx < cy || (cx == cy && x < y);
+        });
+        return m;
+    }
+
+    // builds the subtree over order[lo, hi) whose reference sits at depth `depth`; returns the reference
+    int32_t build(uint32_t lo, uint32_t hi, uint32_t depth)
+    {
+        out->depth = std::max(out->depth, depth);
+        if (hi - lo <= kBvhLeafTris) return leaf_ref(lo, hi);
+        if (depth >= kBvhMaxDepth) throw std::runtime_error("spt_set_mesh_accel: hierarchy depth bound violated");
+        const uint32_t node = (uint32_t)(out->nodes.size() / 4);
+        out->nodes.resize(out->nodes.size() + 4);
+        const uint32_t m = split(lo, hi, kBvhMaxDepth - (depth + 1));
+        const Box l = range_box(lo, m), r = range_box(m, hi);
+        const int32_t lr = build(lo, m, depth + 1), rr = build(m, hi, depth + 1);
+        float4* nd = &out->nodes[4 * (size_t)node];
+        nd[0] = make_float4(l.mn[0], l.mn[1], l.mn[2], l.mx[0]);
+        nd[1] = make_float4(l.mx[1], l.mx[2], r.mn[0], r.mn[1]);
+        nd[2] = make_float4(r.mn[2], r.mx[0], r.mx[1], r.mx[2]);
+        float4 refs = make_float4(0.f, 0.f, 0.f, 0.f);
+        std::memcpy(&refs.x, &lr, 4); std::memcpy(&refs.y, &rr, 4);
+        nd[3] = refs;
+        return (int32_t)node;
+    }
+};
+
+}  // namespace
+
+void build_bvh(const float4* recs, uint32_t ntris, Bvh& out)
+{
+    out = Bvh{};
+    if (ntris >= (1u << 28)) throw std::runtime_error("spt_set_mesh_accel: too many triangles for the leaf encoding");
+    Builder b;
+    b.recs = recs; b.out = &out;
+    b.box.resize(ntris); b.cen.resize(3 * (size_t)ntris); b.order.resize(ntris);
+    std::iota(b.order.begin(), b.order.end(), 0u);
+    for (uint32_t g = 0; g < ntris; ++g) {
+        b.box[g] = padded_box(recs + 3 * (size_t)g);
+        for (int a = 0; a < 3; ++a) b.cen[3 * (size_t)g + a] = 0.5f * b.box[g].mn[a] + 0.5f * b.box[g].mx[a];
+    }
+    out.index.reserve(ntris); out.tris.reserve(3 * (size_t)ntris);
+    if (ntris <= kBvhLeafTris) {
+        // the root is always a node: one leaf with everything, one empty leaf behind an inverted box
+        out.nodes.resize(4);
+        Box l = b.range_box(0, ntris), r; r.clear();
+        if (ntris == 0) l.clear();
+        const int32_t lr = b.leaf_ref(0, ntris), rr = ~(int32_t)0;
+        out.nodes[0] = make_float4(l.mn[0], l.mn[1], l.mn[2], l.mx[0]);
+        out.nodes[1] = make_float4(l.mx[1], l.mx[2], r.mn[0], r.mn[1]);
+        out.nodes[2] = make_float4(r.mn[2], r.mx[0], r.mx[1], r.mx[2]);
+        float4 refs = make_float4(0.f, 0.f, 0.f, 0.f);
+        std::memcpy(&refs.x, &lr, 4); std::memcpy(&refs.y, &rr, 4);
+        out.nodes[3] = refs;
+        out.depth = 1;
+    } else {
+        const int32_t root = b.build(0, ntris, 0);
+        if (root != 0) throw std::runtime_error("spt_set_mesh_accel: internal error (root is not node 0)");
+    }
+    if (out.tris.empty()) out.tris.resize(3, make_float4(0.f, 0.f, 0.f, 0.f));   // never read; keeps the device buffers non-empty
+    if (out.index.empty()) out.index.push_back(0u);
+}
+
+bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why)
+{
+    std::vector<uint32_t> seen(ntris, 0u);
+    struct Item { int32_t ref; uint32_t depth; Box bound; };
+    std::vector<Item> stack;
+    Box all; all.mn[0] = all.mn[1] = all.mn[2] = -INFINITY; all.mx[0] = all.mx[1] = all.mx[2] = INFINITY;
+    if (bvh.nodes.size() < 4 || bvh.nodes.size() % 4) { why = "node array size"; return false; }
+    stack.push_back({0, 0u, all});
+    size_t visited_nodes = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (it.ref < 0) {
+            const uint32_t code = (uint32_t)~it.ref, first = code >> 3, cnt = code & 7u;
+            if (cnt > kBvhLeafTris) { why = "leaf count"; return false; }
+            if (it.depth > kBvhMaxDepth) { why = "leaf deeper than the bound"; return false; }
+            for (uint32_t k = 0; k < cnt; ++k) {
+                if (first + k >= bvh.index.size()) { why = "leaf range"; return false; }
+                const uint32_t g = bvh.index[first + k];
+                if (g >= ntris) { why = "global index"; return false; }
+                ++seen[g];
+                if (std::memcmp(&bvh.tris[3 * (size_t)(first + k)], &recs[3 * (size_t)g], 48) != 0) { why = "leaf record differs from the source record"; return false; }
+                const Box pb = padded_box(recs + 3 * (size_t)g);
+                for (int a = 0; a < 3; ++a)
+                    if (!(pb.mn[a] >= it.bound.mn[a] && pb.mx[a] <= it.bound.mx[a])) { why = "triangle outside its leaf's box"; return false; }
+            }
+            continue;
+        }
+        if ((size_t)it.ref * 4 + 3 >= bvh.nodes.size()) { why = "node index"; return false; }
+        if (++visited_nodes > bvh.nodes.size() / 4) { why = "cycle"; return false; }
+        const float4* nd = &bvh.nodes[4 * (size_t)it.ref];
+        Box l, r;
+        l.mn[0] = nd[0].x; l.mn[1] = nd[0].y; l.mn[2] = nd[0].z; l.mx[0] = nd[0].w; l.mx[1] = nd[1].x; l.mx[2] = nd[1].y;
+        r.mn[0] = nd[1].z; r.mn[1] = nd[1].w; r.mn[2] = nd[2].x; r.mx[0] = nd[2].y; r.mx[1] = nd[2].z; r.mx[2] = nd[2].w;
+        int32_t lr, rr;
+        std::memcpy(&lr, &nd[3].x, 4); std::memcpy(&rr, &nd[3].y, 4);
+        for (const Box* b : {&l, &r})
+            for (int a = 0; a < 3; ++a)
+                if (b->mn[a] <= b->mx[a] && !(b->mn[a] >= it.bound.mn[a] && b->mx[a] <= it.bound.mx[a])) { why = "child box outside its parent's"; return false; }
+        if (it.depth + 1 > kBvhMaxDepth) { why = "node deeper than the bound"; return false; }
+        stack.push_back({lr, it.depth + 1, l});
+        stack.push_back({rr, it.depth + 1, r});
+    }
+    for (uint32_t g = 0; g < ntris; ++g)
+        if (seen[g] != 1u) { why = "triangle " + std::to_string(g) + " referenced " + std::to_string(seen[g]) + " times"; return false; }
+    return true;
+}
+
+}  // namespace spt

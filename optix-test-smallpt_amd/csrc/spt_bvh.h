@@ -1,0 +1,44 @@
+// spt_bvh.h -- host-side builder of the optional bounding-volume hierarchy over a mesh scene's triangles (SPT_ACCEL_BVH).
+//
+// The reference's CPU path tests every triangle (scene.cpp:95-116, smallpt.cpp:443-458); its GPU path hands the same
+// query to OptiX Prime (smallpt.cpp:475-603), whose acceleration structure is not in the repository.  This is the
+// stand-in for the latter: a binary hierarchy with both children's boxes in the parent (one 64-byte node per visit),
+// leaves of <= 4 triangles, depth <= kBvhMaxDepth so that a 32-entry per-lane stack can never overflow.
+//
+// Contract (include/smallpt_mi355x.h, spt_set_mesh_accel): the traversal evaluates the SAME triIntersect arithmetic on
+// the triangles it visits and selects by the same rule (smallest t > 0, lowest (instance, triangle) index among equal
+// t), so it returns the exhaustive loop's hit whenever it visits that triangle.  Boxes are padded by a quarter of the
+// triangle's longest edge (+ 1e-4 of its largest coordinate) and the slab tests are widened, which covers every hit
+// whose ray passes within rounding distance of its triangle; triIntersect has no determinant cut-off, so for a ray
+// lying (to ~1e-7 rad) in a triangle's plane it can also report hits with no geometric relation to the triangle, which
+// no bounding volume contains.  The exhaustive kernel therefore stays the default and the parity anchor; tests compare
+// the two on millions of rays, adversarial ones included.
+#ifndef SPT_BVH_H
+#define SPT_BVH_H
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace spt {
+
+constexpr uint32_t kBvhMaxDepth = 32;      // children of the root are at depth 1; a leaf reference sits at depth <= 32
+constexpr uint32_t kBvhLeafTris = 4;
+
+// Child reference: >= 0 = node index; < 0 = leaf, ~ref = (first leaf-order triangle << 3) | count (count 0 = empty).
+struct Bvh {
+    std::vector<float4> nodes;        // 4 x float4 per node: {lmin.xyz, lmax.x} {lmax.yz, rmin.xy} {rmin.z, rmax.xyz} {left, right, 0, 0}
+    std::vector<float4> tris;         // 3 x float4 per triangle in leaf order (the records of MParams::tris)
+    std::vector<uint32_t> index;      // global (instance-major) triangle index of every leaf-order triangle
+    uint32_t depth = 0, leaves = 0;
+};
+
+// recs: ntris x 3 records {v0, n.x} {v1 - v0, n.y} {v2 - v0, n.z}.  Throws std::runtime_error on non-finite vertices.
+void build_bvh(const float4* recs, uint32_t ntris, Bvh& out);
+// Structural check used by the CPU tests: every triangle in exactly one leaf, every box contains its subtree's padded
+// triangles, depth bound respected.  Returns false and a reason on failure.
+bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why);
+
+}  // namespace spt
+#endif

@@ -45,6 +45,12 @@ int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32
  * op 10 of spt_selftest_math evaluates sqrt_rsq elementwise. */
 int  spt_selftest_range(spt_ctx* ctx, int op, uint32_t first, uint32_t count, uint64_t* mismatches, uint32_t* first_bad);
 
+/* Host-only self-test of the SPT_ACCEL_BVH builder (csrc/spt_bvh.cpp; no device call, runs without a GPU): builds the
+ * hierarchy over the meshes' triangles and checks that every triangle sits in exactly one leaf, that every box contains
+ * the padded triangles below it and that no reference lies deeper than the 32-entry traversal stack allows.
+ * out4 = {nodes, leaves, depth, triangles}; returns 0 = valid, 2 = invalid (reason in `why`), 1 = builder error. */
+int  spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, char* why, uint32_t why_len);
+
 #ifdef __cplusplus
 }
 #endif

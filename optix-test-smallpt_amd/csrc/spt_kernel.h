@@ -49,11 +49,15 @@ struct MParams {
     const uint32_t* inst_first_tri;// first global triangle of every instance
     const float4* mats;            // 3 rows per instance, as for spheres
     uint32_t ntris, ninst;
+    // optional hierarchy (SPT_ACCEL_BVH, spt_bvh.h); null = the exhaustive loop
+    const float4* bvh_nodes;       // 4 per node: both children's boxes + their references
+    const float4* bvh_tris;        // the records of `tris` in leaf order
+    const uint32_t* bvh_index;     // global triangle index of every leaf-order triangle
 };
 
 }  // namespace spt
 
-extern "C" size_t spt_mesh_lds_bytes(void);
+extern "C" size_t spt_mesh_lds_bytes(int bvh);
 extern "C" size_t spt_mesh_stack_floats(uint32_t blocks);
 extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_rays, uint64_t nrays, float* d_hits, hipStream_t stream);

@@ -13,8 +13,11 @@
 //     (48 B) are staged through LDS in tiles by the whole workgroup and read back wave-uniformly (broadcast).
 //   * meshkernel: one lane = one path, one task = one D9 sample block of a jitter cell, same RNG / accumulation order /
 //     shading decisions (D1-D19) as the sphere kernels; hit.n is the interpolated, un-normalised vertex normal exactly
-//     as makeHit returns it.  This is the reference's actual direction of travel (OptiX triangles); an LDS/BVH traversal
-//     kernel is what comes next, the brute-force loop is the correctness anchor.
+//     as makeHit returns it.  This is the reference's actual direction of travel (OptiX triangles); the exhaustive loop is
+//     the default and the correctness anchor.
+//   * SPT_ACCEL_BVH (opt-in, spt_bvh.h): the same query by a per-lane stack traversal of a padded binary hierarchy -- same
+//     triIntersect arithmetic on the visited triangles, same selection rule (smallest t > 0, lowest global index among
+//     equal t) -- the stand-in for the OptiX Prime traversal of smallpt.cpp:475-603.
 #include "spt_device.h"
 #include "spt_kernel.h"
 
@@ -87,6 +90,66 @@ __device__ __forceinline__ uint32_t closest_triangle(const float4* __restrict__ 
     return near_tri;
 }
 
+// The same query through the hierarchy (spt_bvh.h).  Per lane: a stack of <= 32 child references in LDS (entry e of thread
+// t at s_stack[e * blockDim + t]: conflict-free), near child first, both children's padded boxes tested against the ray
+// segment [0, current nearest] with widened slabs (a box is only skipped when the ray misses it by more than the widening;
+// NaN from 0 * inf drops out of v_min/v_max, which is the conservative side).  A triangle replaces the current hit when its
+// key is smaller, or equal with a lower global index: the (instance, triangle)-ascending strict '<' of the reference's loops.
+__device__ __forceinline__ uint32_t closest_triangle_bvh(const MParams& M, uint32_t* s_stack, bool active, f3 ro, f3 rd, float& t_out)
+{
+    uint32_t near_key = kMeshInfKey, near_tri = 0xFFFFFFFFu;
+    if (active) {
+        const f3 iv = mk(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));   // 1 ulp; inside the widening
+        float tcut = 1e20f;                                        // widened distance of the current nearest hit
+        uint32_t sp = 0;
+        int cur = 0;                                               // the root is always node 0
+        for (;;) {
+            if (cur >= 0) {
+                const float4* nd = M.bvh_nodes + 4 * (size_t)cur;
+                const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                const float lx0 = (a.x - ro.x) * iv.x, lx1 = (a.w - ro.x) * iv.x;
+                const float ly0 = (a.y - ro.y) * iv.y, ly1 = (b.x - ro.y) * iv.y;
+                const float lz0 = (a.z - ro.z) * iv.z, lz1 = (b.y - ro.z) * iv.z;
+                const float rx0 = (b.z - ro.x) * iv.x, rx1 = (c.y - ro.x) * iv.x;
+                const float ry0 = (b.w - ro.y) * iv.y, ry1 = (c.z - ro.y) * iv.y;
+                const float rz0 = (c.x - ro.z) * iv.z, rz1 = (c.w - ro.z) * iv.z;
+                const float ln = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)), __builtin_fminf(lz0, lz1));
+                const float lf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)), __builtin_fmaxf(lz0, lz1));
+                const float rn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)), __builtin_fminf(rz0, rz1));
+                const float rf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)), __builtin_fmaxf(rz0, rz1));
+                const bool hl = (lf >= 0.f) & (ln <= lf * 1.0001f) & (ln <= tcut);
+                const bool hr = (rf >= 0.f) & (rn <= rf * 1.0001f) & (rn <= tcut);
+                const int lref = __float_as_int(d.x), rref = __float_as_int(d.y);
+                if (hl & hr) {
+                    const bool left_first = ln <= rn;
+                    s_stack[sp * kMeshBlock + threadIdx.x] = (uint32_t)(left_first ? rref : lref);
+                    ++sp;
+                    cur = left_first ? lref : rref;
+                    continue;
+                }
+                if (hl | hr) { cur = hl ? lref : rref; continue; }
+            } else {
+                const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = code & 7u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4* r = M.bvh_tris + 3 * (size_t)(first + k);
+                    float u, v;
+                    const float t = tri_test(r[0], r[1], r[2], ro, rd, u, v);
+                    const uint32_t key = __float_as_uint(t) - 1u;
+                    const uint32_t g = M.bvh_index[first + k];
+                    if (key < near_key || (key == near_key && g < near_tri)) {      // key == kMeshInfKey never replaces: near_tri would have to be larger
+                        if (key < kMeshInfKey) { near_key = key; near_tri = g; tcut = t * 1.0001f; }
+                    }
+                }
+            }
+            if (sp == 0u) break;
+            --sp;
+            cur = (int)s_stack[sp * kMeshBlock + threadIdx.x];
+        }
+    }
+    t_out = __uint_as_float(near_key + 1u);
+    return near_tri;
+}
+
 struct MeshHit { float dist; uint32_t inst, tri; f3 x, n; float u, v; };
 
 // makeHit(instId, mesh, meshHit), scene.cpp:73-93, for the winning triangle (u, v re-evaluated from its record)
@@ -106,6 +169,7 @@ __device__ __forceinline__ MeshHit make_hit(const MParams& M, uint32_t tri, floa
 }
 
 // Intersector::traceRays (smallpt.cpp:460-470 / :553-587): one Hit (scene.h:31-43, 44 bytes) per ray.
+template <bool BVH>
 __global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const float* __restrict__ rays, uint64_t nrays, float* __restrict__ hits)
 {
     extern __shared__ float4 s_tile[];
@@ -114,7 +178,8 @@ __global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const 
     f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (active) { ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]); rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]); }
     float t;
-    const uint32_t tri = closest_triangle(M.tris, M.ntris, s_tile, active, ro, rd, t);
+    const uint32_t tri = BVH ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), active, ro, rd, t)
+                             : closest_triangle(M.tris, M.ntris, s_tile, active, ro, rd, t);
     if (!active) return;
     float* h = hits + 11 * i;
     if (tri == 0xFFFFFFFFu) {                                                    // Hit{}: dist = inf (smallpt.cpp:454-455)
@@ -130,6 +195,7 @@ __global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const 
 // ---- path tracer over the mesh scene ------------------------------------------------------------------------------
 struct MPath { f3 o, d, w; uint32_t depth, branch, rbase; };
 
+template <bool BVH>
 __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const MParams M)
 {
     extern __shared__ float4 s_tile[];
@@ -218,7 +284,8 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
 
         // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
         float t;
-        const uint32_t tri = closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
+        const uint32_t tri = BVH ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
+                                 : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
         if (alive) {
             ++nbounce;
             if (tri == 0xFFFFFFFFu) {
@@ -310,19 +377,21 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
 
 }  // namespace spt
 
-extern "C" size_t spt_mesh_lds_bytes(void) { return (size_t)spt::kTile * 48u; }
+// exhaustive: one tile of triangle records; hierarchy: 32 stack entries per thread
+extern "C" size_t spt_mesh_lds_bytes(int bvh) { return bvh ? (size_t)spt::kMeshBlock * 32u * 4u : (size_t)spt::kTile * 48u; }
 extern "C" size_t spt_mesh_stack_floats(uint32_t blocks) { return (size_t)blocks * spt::kMeshBlock * 36u; }
 
 extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream)
 {
-    const size_t lds = spt_mesh_lds_bytes();
-    hipLaunchKernelGGL(spt::meshkernel, dim3(blocks), dim3(spt::kMeshBlock), lds, stream, *K, *M);
+    if (M->bvh_nodes) hipLaunchKernelGGL(spt::meshkernel<true>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(1), stream, *K, *M);
+    else hipLaunchKernelGGL(spt::meshkernel<false>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(0), stream, *K, *M);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_rays, uint64_t nrays, float* d_hits, hipStream_t stream)
 {
     const uint64_t blocks = (nrays + spt::kMeshBlock - 1) / spt::kMeshBlock;
-    hipLaunchKernelGGL(spt::trace_rays, dim3((unsigned)blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(), stream, *M, d_rays, nrays, d_hits);
+    if (M->bvh_nodes) hipLaunchKernelGGL(spt::trace_rays<true>, dim3((unsigned)blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(1), stream, *M, d_rays, nrays, d_hits);
+    else hipLaunchKernelGGL(spt::trace_rays<false>, dim3((unsigned)blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(0), stream, *M, d_rays, nrays, d_hits);
     return hipGetLastError();
 }

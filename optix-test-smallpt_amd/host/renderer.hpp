@@ -74,6 +74,9 @@ public:
         }
         check(spt_set_meshes(ctx_, ms.data(), (uint32_t)ms.size(), mats.data()));
     }
+    // CPUIntersector (every triangle: SPT_ACCEL_EXHAUSTIVE, the default) or the OptixIntersector's acceleration structure
+    // (rtpModelUpdate, smallpt.cpp:520-530: SPT_ACCEL_BVH); contract in include/smallpt_mi355x.h
+    void setMeshAccel(int accel) { check(spt_set_mesh_accel(ctx_, accel)); }
     std::vector<Hit> traceRays(const Ray* rays, size_t n)
     {
         std::vector<Hit> hits(n);

@@ -5,6 +5,7 @@
 //
 //   smallpt_mi355x [spp] [--scene file.json | shipped-meshes] [--size WxH] [--seed N] [--out image.ppm] [--device D]
 //                  [--dump-scene out.json] [--parse-only]
+//                  [--accel bvh|exhaustive]                    mesh scenes: OptixIntersector-style hierarchy or every triangle (default)
 //                  [--devices 0,1,...] [--self-exchange]      row bands over several GPUs + RCCL exchange (MultiRenderer)
 //   smallpt_mi355x [spp] --viewer [--frames N] [--request JSON] [--frames-after M] [--threaded] [--org x,y,z]
 //                  [--dump-raw accum.bin]                      main()'s progressive loop (smallpt.cpp:840-1005) without the
@@ -28,6 +29,7 @@ int main(int argc, char* argv[])
 {
     int spp = 4, w = 256, h = 256, device = 0;       // smallpt.cpp:274-276 defaults
     unsigned long long seed = 0;
+    int accel = SPT_ACCEL_EXHAUSTIVE;
     std::string scene_path, out_path = "image.ppm", dump_path;
     bool single_triangle = false;
     bool parse_only = false, viewer = false, threaded = false, self_exchange = false;
@@ -55,6 +57,7 @@ int main(int argc, char* argv[])
                 return 0;
             } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
         }
+        else if (a == "--accel") { const std::string m = next(); if (m == "bvh") accel = SPT_ACCEL_BVH; else if (m == "exhaustive") accel = SPT_ACCEL_EXHAUSTIVE; else { std::fprintf(stderr, "--accel bvh|exhaustive\n"); return 2; } }
         else if (a == "--single-triangle") single_triangle = true;   // SingleTriangleScene of main(), smallpt.cpp:818-832
         else if (a == "--viewer") viewer = true;
         else if (a == "--threaded") threaded = true;
@@ -73,6 +76,7 @@ int main(int argc, char* argv[])
         realize_meshes(scene);
         auto upload = [&](Renderer& rr) {          // spheres, or the Intersector seam for a mesh scene
             if (scene.meshes.empty()) { rr.setScene(scene.spheres); return; }
+            rr.setMeshAccel(accel);
             std::vector<TriMesh> ms; std::vector<Material> mats;
             for (const MeshInstance& m : scene.meshes) { ms.push_back(m.mesh); mats.push_back(m.material); }
             rr.setMeshes(ms, mats);

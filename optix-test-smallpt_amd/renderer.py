@@ -13,6 +13,7 @@ from ._lib import SptCamera, SptMaterial, SptMesh, SptMultiStats, SptStats, load
 from .scene import HIT_DTYPE, RAY_DTYPE, SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
+ACCEL_EXHAUSTIVE, ACCEL_BVH = 0, 1
 
 
 class SptError(RuntimeError):
@@ -104,6 +105,11 @@ class Renderer:
             mats[i].color = (C.c_float * 3)(*[float(v) for v in col])
             mats[i].refl = int(refl)
         self._check(self._lib.spt_set_meshes(self._h, ms, len(meshes), mats))
+
+    def set_mesh_accel(self, accel):
+        """ACCEL_EXHAUSTIVE (default: every triangle, bit-identical to the reference's loops) or ACCEL_BVH (the role of the
+        reference's OptiX Prime model, smallpt.cpp:475-603; contract in include/smallpt_mi355x.h)."""
+        self._check(self._lib.spt_set_mesh_accel(self._h, int(accel)))
 
     def trace_rays(self, rays):
         """Intersector::traceRays (smallpt.cpp:460-470): rays = array of RAY_DTYPE (or (n, 6) floats); returns HIT_DTYPE[n]."""

@@ -141,3 +141,149 @@ def test_cpp_cli_renders_mesh_scenes(pkg, oracle, tmp_path):
     mats = [((0, 0, 0), (.75, .25, .25), pkg.DIFF), ((1, 1, 1), (0, 0, 0), pkg.DIFF)]
     ref, _ = oracle.render_meshes(meshes, mats, 24, 16, 1, seed=2, normalise=True)
     assert out.read_bytes() == expected_ppm(oracle, ref) and ref.max() > 0
+    out2 = tmp_path / "m_bvh.ppm"                                   # the same through the hierarchy (OptixIntersector's role)
+    r = subprocess.run([cli, "4", "--scene", "shipped-meshes", "--accel", "bvh", "--size", "24x16", "--seed", "2", "--out", str(out2)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert out2.read_bytes() == out.read_bytes()
+
+
+# ---- SPT_ACCEL_BVH: the optional hierarchy (the OptiX Prime model's role, smallpt.cpp:475-603) ----
+def _selftest_bvh(pkg, meshes):
+    import ctypes as C
+    lib = pkg.load_library()
+    ms = (pkg.SptMesh * max(1, len(meshes)))()
+    for i, m in enumerate(meshes):
+        ms[i].positions, ms[i].normals, ms[i].indices = m.positions.ctypes.data, m.normals.ctypes.data, m.indices.ctypes.data
+        ms[i].nverts, ms[i].ntris = len(m.positions), len(m.indices)
+    out, why = (C.c_uint32 * 4)(), C.create_string_buffer(256)
+    rc = lib.spt_selftest_bvh(ms, len(meshes), C.byref(out), why, 256)
+    return rc, list(out), why.value.decode()
+
+
+def _soup(pkg, n, seed, flat=False):
+    """n random triangles: sizes over three decades, positions over two; flat=True puts them all into one plane (every
+    centroid split degenerates on one axis, many coincide)."""
+    rs = np.random.RandomState(seed)
+    c = rs.uniform(-50, 50, (n, 1, 3)) * (10 ** rs.uniform(-1, 0, (n, 1, 1)))
+    v = c + rs.normal(size=(n, 3, 3)) * (10 ** rs.uniform(-2, 1, (n, 1, 1)))
+    if flat:
+        v[:, :, 1] = 3.0
+    pos = v.reshape(-1, 3).astype(np.float32)
+    nor = np.tile(np.array([0, 1, 0], dtype=np.float32), (len(pos), 1))
+    return pkg.TriMesh(pos, nor, np.arange(3 * n, dtype=np.uint32).reshape(n, 3))
+
+
+def test_bvh_builder_structure(pkg):
+    """Host-side invariants of the hierarchy (no GPU): every triangle in exactly one leaf of <= 4, every box contains the
+    padded triangles below it, no reference deeper than the traversal's 32-entry stack; degenerate inputs included."""
+    S = pkg.make_sphere_trimesh
+    tri = pkg.single_triangle_scene()[0][0]
+    same = pkg.TriMesh(np.tile(tri.positions, (300, 1)), np.tile(tri.normals, (300, 1)), np.arange(900, dtype=np.uint32).reshape(300, 3))
+    cases = {"empty": [], "one": [tri], "three": [tri, tri, tri], "five": [tri] * 5, "300 identical": [same],
+             "shipped": [S((-1, 0, -4), 1.0), S((1.5, 0, -5), 1.0)], "mixed sizes": [S((0, -1e3 - 2, -6), 1e3, 24), S((0, 0, 0), 0.01, 8), tri],
+             "soup": [_soup(pkg, 20000, 1)], "flat soup": [_soup(pkg, 5000, 2, flat=True)]}
+    for name, meshes in cases.items():
+        rc, (nodes, leaves, depth, ntris), why = _selftest_bvh(pkg, meshes)
+        assert rc == 0, (name, rc, why)
+        assert ntris == sum(m.triangle_count for m in meshes) and depth <= 32 and nodes >= 1, (name, nodes, leaves, depth, ntris)
+        if ntris > 4:
+            assert leaves >= (ntris + 3) // 4 and nodes == leaves - 1, (name, nodes, leaves)
+    rc, _, why = _selftest_bvh(pkg, [pkg.TriMesh(np.array([[0, 0, 0], [1, 0, 0], [np.inf, 1, 0]], dtype=np.float32), tri.normals, tri.indices)])
+    assert rc == 1 and "non-finite" in why
+
+
+def _adversarial_rays(meshes, rs, n_random):
+    """Random rays plus the ones a padded hierarchy could get wrong: aimed exactly at vertices, edge midpoints and
+    centroids (from outside and from a vertex itself), axis-parallel, grazing along triangle planes, origins on surfaces."""
+    pos = np.concatenate([m.positions for m in meshes]).astype(np.float64)
+    tri = np.concatenate([m.positions[m.indices.reshape(-1, 3)] for m in meshes]).astype(np.float64)     # (T, 3, 3)
+    lo, hi = pos.min(0), pos.max(0)
+    ext = np.maximum(hi - lo, 1e-3)
+    rays = []
+    o = rs.uniform(lo - ext, hi + ext, (n_random, 3)); d = rs.normal(size=(n_random, 3))
+    rays.append(np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1))
+    k = min(len(tri), 4000)
+    pick = tri[rs.choice(len(tri), k, replace=len(tri) < k)]
+    eye = rs.uniform(lo - ext, hi + ext, (k, 3))
+    targets = [pick[:, 0], 0.5 * (pick[:, 0] + pick[:, 1]), pick.mean(1), pick[:, 2]]
+    for t in targets:
+        d = t - eye
+        rays.append(np.concatenate([eye, d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)], axis=1))
+    d = pick[:, 1] - pick[:, 0]                                                       # along an edge, starting on / before the vertex
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    rays.append(np.concatenate([pick[:, 0], d], axis=1))
+    rays.append(np.concatenate([pick[:, 0] - 3 * d, d], axis=1))
+    n = np.cross(pick[:, 1] - pick[:, 0], pick[:, 2] - pick[:, 0])
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
+    for eps in (1e-2, 1e-4, 1e-6, 0.0):                                               # grazing: in the triangle's plane, tilted by eps
+        g = d + eps * n
+        rays.append(np.concatenate([pick.mean(1) - 2 * g, g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)], axis=1))
+    for ax in range(3):                                                               # axis-parallel (zero direction components)
+        for sgn in (1.0, -1.0):
+            d = np.zeros((k, 3)); d[:, ax] = sgn
+            o = pick.mean(1).copy(); o[:, ax] -= sgn * 2 * ext[ax]
+            rays.append(np.concatenate([o, d], axis=1))
+            rays.append(np.concatenate([pick[:, 1] - 2 * ext[ax] * d, d], axis=1))    # through a vertex
+    rays.append(np.concatenate([pick.mean(1), n], axis=1))                            # origin on the surface
+    return np.concatenate(rays).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_bvh_trace_rays_equals_exhaustive(pkg, renderer):
+    """spt_trace_rays through the hierarchy returns, bit for bit, the Hit of the exhaustive loop (itself equal to the
+    oracle's, test above) on random and adversarial rays over five kinds of scene -- except for rays lying in the plane of
+    the triangle they are reported to hit, where the reference's arithmetic returns noise (checked to be the only exception)."""
+    S = pkg.make_sphere_trimesh
+    rs = np.random.RandomState(11)
+    scenes = {"shipped": [S((-1, 0, -4), 1.0), S((1.5, 0, -5), 1.0)], "cornell-like": _mesh_scene(pkg)[0],
+              "soup": [_soup(pkg, 3000, 4)], "flat soup + ball": [_soup(pkg, 1500, 5, flat=True), S((0, 3, 0), 2.0, 8)],
+              "one": [pkg.single_triangle_scene()[0][0]]}
+    total = in_plane = 0
+    try:
+        for name, meshes in scenes.items():
+            mats = [((0, 0, 0), (.5, .5, .5), pkg.DIFF)] * len(meshes)
+            rays = _adversarial_rays(meshes, rs, 150000 if name == "shipped" else 60000)
+            renderer.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
+            renderer.set_meshes(meshes, mats)
+            ref = renderer.trace_rays(rays)
+            renderer.set_mesh_accel(pkg.ACCEL_BVH)
+            got = renderer.trace_rays(rays)
+            bad = np.unique(np.nonzero(got.view(np.uint8).reshape(len(rays), -1) != ref.view(np.uint8).reshape(len(rays), -1))[0])
+            # The one documented exception (include/smallpt_mi355x.h): the exhaustive loop reports a triangle whose determinant
+            # dot(rd, cross(e1, e2)) is zero to rounding -- a ray lying in the triangle's plane (the "along an edge" and
+            # "tilt 0 / 1e-6" families above are built to do that) or a zero-area triangle (the needles makeSphereTriMesh puts
+            # at the poles, hit by the rays aimed at their vertices).  triIntersect divides by it (scene.cpp:62), so the
+            # reported distance is rounding noise (seen: a vertex 3.0 away reported at 2.0 by one triangle and at 2.96 by
+            # its neighbour) and need not lie in any box.
+            tri = np.concatenate([m.positions[m.indices.reshape(-1, 3)] for m in meshes]).astype(np.float64)
+            first = np.cumsum([0] + [m.triangle_count for m in meshes])
+            for i in bad:
+                assert ref["dist"][i] < 1e20, (name, rays[i], got[i], ref[i])                 # a hit may only be lost, never invented
+                t = tri[first[ref["instId"][i]] + ref["triId"][i]]
+                e1, e2 = t[1] - t[0], t[2] - t[0]
+                det = abs(float(rays[i, 3:].astype(np.float64) @ np.cross(e1, e2)))           # what triIntersect divides by (scene.cpp:62)
+                assert det < 1e-5 * np.linalg.norm(e1) * np.linalg.norm(e2), (name, det, rays[i], got[i], ref[i])
+            assert len(bad) <= len(rays) // 500, (name, len(bad))
+            assert (ref["dist"] < 1e20).sum() > len(rays) // 50, name
+            total += len(rays); in_plane += len(bad)
+    finally:
+        renderer.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
+    assert total > 400000
+    print(f"hierarchy == exhaustive on {total - in_plane} of {total} rays; {in_plane} in-plane rays differ")
+
+
+@pytest.mark.gpu
+def test_bvh_render_equals_exhaustive_and_oracle(pkg, renderer, oracle):
+    """The mesh path tracer through the hierarchy: same image, same bounce count as the exhaustive kernel and the oracle."""
+    meshes, mats = _mesh_scene(pkg)
+    w, h, samps, seed = 40, 30, 2, 5
+    ref, rst = oracle.render_meshes(meshes, mats, w, h, samps, seed=seed)
+    try:
+        for accel in (pkg.ACCEL_EXHAUSTIVE, pkg.ACCEL_BVH):
+            renderer.set_mesh_accel(accel)
+            renderer.set_meshes(meshes, mats)                # the hierarchy is (re)built with the meshes
+            img, st = renderer.render(w, h, samps, seed=seed)
+            assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"], accel
+    finally:
+        renderer.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
+        renderer.set_scene(pkg.cornell9())

@@ -50,3 +50,17 @@ def test_oracle_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "oracle sanitizer run ok" in r.stdout
+
+
+def test_bvh_builder_under_asan_ubsan(tmp_path):
+    """The host-side hierarchy builder of SPT_ACCEL_BVH (csrc/spt_bvh.cpp is plain C++: compiled here with g++ against the HIP
+    vector-type headers only)."""
+    if not _sanitizers_work(tmp_path):
+        pytest.skip("libasan/libubsan not usable in this environment")
+    exe = tmp_path / "bvh_san"
+    subprocess.check_call(["g++", "-std=c++17", *SAN, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "sanitize", "bvh_main.cpp"),
+                           os.path.join(ROOT, "optix-test-smallpt_amd", "csrc", "spt_bvh.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "bvh sanitizer run ok 44" in r.stdout

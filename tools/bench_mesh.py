@@ -18,9 +18,12 @@ import oracle_binding as orc  # noqa: E402
 PEAK = 157.3
 
 
-def run(name, meshes, mats, w, h, samps, camera, rows):
+def run(name, meshes, mats, w, h, samps, camera, rows, accel=0):
     r = pkg.Renderer(0)
+    r.set_mesh_accel(accel)
+    t0 = time.perf_counter()
     r.set_meshes(meshes, mats)
+    setup_ms = (time.perf_counter() - t0) * 1e3
     ntri = sum(m.triangle_count for m in meshes)
     r.render(w, h, samps, seed=0, normalise=True, camera=camera)
     best = None
@@ -33,8 +36,8 @@ def run(name, meshes, mats, w, h, samps, camera, rows):
     for row in rows:
         ref, _ = orc.render_meshes(meshes, mats, w, h, samps, seed=0, normalise=True, row_begin=row, row_count=1, camera=camera)
         exact &= bool(np.array_equal(img[row:row + 1], ref))
-    tests = st["bounces"] * ntri
-    out = {"config": name, "triangles": ntri, "image": f"{w}x{h}", "spp": 4 * samps, "kernel_ms": round(st["kernel_ms"], 3),
+    tests = st["bounces"] * ntri                 # what the exhaustive loop evaluates; with the hierarchy: the work it replaces
+    out = {"config": name, "accel": "bvh" if accel else "exhaustive", "set_meshes_ms": round(setup_ms, 2), "triangles": ntri, "image": f"{w}x{h}", "spp": 4 * samps, "kernel_ms": round(st["kernel_ms"], 3),
            "msamples_s": round(st["samples"] / st["kernel_ms"] / 1e3, 2), "mrays_s": round(st["bounces"] / st["kernel_ms"] / 1e3, 2),
            "bounces_per_sample": round(st["bounces"] / st["samples"], 3),
            "gtests_s": round(tests / st["kernel_ms"] / 1e6, 1), "tflops_triIntersect": round(tests * 52 / st["kernel_ms"] / 1e9, 2),
@@ -51,6 +54,13 @@ def main():
     mats = [((0, 0, 0), (.75, .25, .25), pkg.DIFF), ((1, 1, 1), (0, 0, 0), pkg.DIFF)]
     rows.append(run("f4: the reference's shipped scene, 2 tessellated spheres, cpuRender camera, 4 spp", meshes, mats, 256, 256, 1, None, [100, 200]))
     rows.append(run("f4: same scene, 256 spp (lanes regenerate paths: the steady-state rate)", meshes, mats, 256, 256, 64, None, [128]))
+    # the same through the hierarchy (SPT_ACCEL_BVH: the OptiX Prime model's role, smallpt.cpp:475-603), and at the viewer's size
+    rows.append(run("f4: shipped scene, 4 spp, hierarchy", meshes, mats, 256, 256, 1, None, [100, 200], accel=1))
+    rows.append(run("f4: shipped scene, 256 spp, hierarchy", meshes, mats, 256, 256, 64, None, [128], accel=1))
+    rows.append(run("f4: shipped scene at the viewer's 1280x720, 4 spp, hierarchy", meshes, mats, 1280, 720, 1, None, [360], accel=1))
+    big = [pkg.make_sphere_trimesh((50, 40.8, 81.6), 10.0, 256), pkg.make_sphere_trimesh((50, 681.6 - .27, 81.6), 600.0, 256)]
+    rows.append(run("f4: the two spheres at subdivision 256 (2 x 262144 triangles), 1280x720, 4 spp, hierarchy (oracle rows skipped: "
+                    "0.5 M triangles per ray on the CPU)", big, mats, 1280, 720, 1, None, [], accel=1))
     meshes, mats = pkg.single_triangle_scene()
     rows.append(run("f4: SingleTriangleScene of main(), viewer camera", meshes, mats, 1280, 720, 1, pkg.pinhole_camera(), [300, 500]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
