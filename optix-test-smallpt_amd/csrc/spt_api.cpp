@@ -63,7 +63,7 @@ struct spt_ctx {
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
     float* d_frame = nullptr;
     uint32_t prog_w = 0, prog_h = 0;
-    unsigned long long pool_stats[15] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
+    unsigned long long pool_stats[24] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
     size_t cells_cap = 0;          // in float4
@@ -78,7 +78,7 @@ struct spt_ctx {
     // last launch
     bool pending = false;
     spt_stats last{};
-    unsigned long long diag[15] = {};   // DIAG build only: phase wave-times and lane counts (pool kernel: its statistics)
+    unsigned long long diag[24] = {};   // DIAG build only: phase wave-times and lane counts (pool kernel: its statistics)
     std::string error;
 
     int fail(const char* fmt, ...)
@@ -830,15 +830,14 @@ int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
 }
 
 // Diagnostic (tuning variant bit 8): per-phase wave-time sums [0..7], iterations, lane counts of the last launch.
-int spt_diag(spt_ctx* c, unsigned long long* out15)
+int spt_diag(spt_ctx* c, unsigned long long* out24)
 {
-    if (!c || !out15) return 1;
+    if (!c || !out24) return 1;
     if (c->last_was_pool) {
-        std::memset(out15, 0, sizeof c->diag);
-        std::memcpy(out15, c->pool_stats, sizeof c->pool_stats);
+        std::memcpy(out24, c->pool_stats, sizeof c->pool_stats);
         return 0;
     }
-    std::memcpy(out15, c->diag, sizeof c->diag);
+    std::memcpy(out24, c->diag, sizeof c->diag);
     return 0;
 }
 

@@ -18,15 +18,15 @@ extern "C" {
  * would run, bits 12:11 = pool slots per wave (0: 160, 3: 128; 1: 96 and 2: 192 in -DSPT_POOL_SIZES builds).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
 /* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
- * out15[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters. */
-int  spt_diag(spt_ctx* ctx, unsigned long long* out15);
+ * out24[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters (24 words are written). */
+int  spt_diag(spt_ctx* ctx, unsigned long long* out24);
 
 /* Pool kernel only: a wave gives up `seconds` after its start (0 = never; default).  A launch in which that happened
  * makes spt_sync fail instead of returning an incomplete image.  Tests set a few seconds so that a scheduling bug
  * cannot hang the GPU box. */
 int  spt_set_watchdog(spt_ctx* ctx, double seconds);
 /* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip).
- * After a pool launch spt_diag returns out15[0..2] = batches per class (GEN, DIFF, REFR), [3..5] = lanes per class. */
+ * After a pool launch spt_diag returns out24[0..2] = batches per class (GEN, DIFF, REFR), [3..5] = lanes per class. */
 int  spt_last_kernel(spt_ctx* ctx);
 
 /* Numerics self-test of the kernel's exact-math helpers (host arrays in/out, n elements):

@@ -135,7 +135,16 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     uint32_t dry_lo = 0, dry_hi = 0;                             // when this wave found the task queue empty: written once, read once,
                                                                  // so parked in vector registers rather than in scarce scalar ones
 
+#ifdef SPT_POOL_PHASES
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};                  // select+pop, class code, closest hit, post, push (lone-path latency study)
+#define PH_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
+#else
+#define PH_STAMP(i)
+#endif
     for (;;) {
+#ifdef SPT_POOL_PHASES
+        unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#endif
         // ---- choose the class of this batch: a full batch of the rarest class first, else the longest list ----
         uint32_t c, b, lbase;
         if (nR >= 64u) c = C_REFR;
@@ -165,6 +174,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         bool has_ray = false;
         bool retired = false;                                    // GEN only: no task left for this slot
 
+        PH_STAMP(0)
         if (c == C_GEN) {
             // ================= GEN: continue the slot's task (smallpt.cpp:304-340, :252 pop) =================
             const uint2 ts = gtask[slot];
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             const f3 n = normalize<false>(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));       // scene.cpp:124
             const f3 nl = dot(n, din) < 0 ? n : neg(n);                                     // :174 (D2)
             if (c == C_DIFF) {
-                const bool is_diff = ((pk >> 28) & 3u) == 0u;
+                const bool is_diff = valid && ((pk >> 28) & 3u) == 0u;   // idle lanes (pk = 0) must not drag a mirror-only batch through the diffuse code
                 o = hx + nl * 0.02f;                                                        // :172 (D3)
                 if (is_diff) {                                                              // DIFF :208-215
                     const uint32_t u1bits = rng_draw_bits(rbase + kGolden, k1);
@@ -379,6 +389,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         // compare; det < 0 gives NaN keys that never win (see spt_kernel.hip phase D1).  The table is padded by the host
         // to 3 * NG spheres with never-hit entries (r*r = -inf: det = -inf, NaN keys), so the loop is fully unrolled
         // without bounds tests; ascending index with strict '<' = lowest index wins ties.
+        PH_STAMP(1)
         nbounce += (unsigned long long)__popcll(__ballot(has_ray));
         uint32_t next = C_GEN;                                   // slots without a continuing path go back to GEN
         const bool queued = valid && !retired;
@@ -448,12 +459,14 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             for (int i = 1; i < 3 * NG; ++i)
                 if (nk[i + 1] != nk[i]) inst = (uint32_t)i;
         }
+        PH_STAMP(2)
         if (has_ray) {
             // ---- class-independent part of shadePaths (smallpt.cpp:168-198) ----
             if (near_key != kInfKeyP) {                                                     // else :168 miss (D13)
                 const float t = __uint_as_float(near_key + kEpsBias);
                 const float4 me = s_mat[3 * inst + 0];                                      // emission.xyz, refl | emissive << 2
                 const float4 mc = s_mat[3 * inst + 1];                                      // color.xyz, pmax
+                const float4 mf = s_mat[3 * inst + 2];                                      // color * (1/pmax), :192: read with the others (one LDS round trip)
                 const uint32_t rb = __float_as_uint(me.w);
                 const uint32_t refl = rb & 3u;
                 if ((rb & 4u) != 0u || (branchf & 8u) != 0u) {                              // :179 (D4); + w*0 is skipped, exact for finite w
@@ -463,7 +476,6 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 bool cont = true;
                 if (depth > 5u) {                                                           // :188 (D5)
                     if (rng_draw(rbase, k1) < mc.w) {
-                        const float4 mf = s_mat[3 * inst + 2];                              // color * (1/pmax), :192
                         f = mk(mf.x, mf.y, mf.z);
                     } else {
                         cont = false;                                                       // :196
@@ -486,6 +498,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                 }
             }
         }
+        PH_STAMP(3)
         // ================= push every slot onto the list of its next class =================
         {
             const bool to_gen = queued && next == C_GEN;
@@ -502,6 +515,7 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             nD += (uint32_t)__popcll(md);
             nR += (uint32_t)__popcll(mr);
         }
+        PH_STAMP(4)
     }
 
     // stats: one atomic per wave
@@ -523,6 +537,10 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         const unsigned long long t_dry = ((unsigned long long)uni(dry_hi) << 32) | uni(dry_lo);
         if (t_dry) { atomicMax(&K.counters[13], t_end - t_dry); atomicAdd(&K.counters[14], t_end - t_dry); }
         atomicAdd(&K.counters[15], t_end - t_start);
+#ifdef SPT_POOL_PHASES
+        for (int i = 0; i < 5; ++i) atomicAdd(&K.counters[17 + i], ph[i]);
+        atomicAdd(&K.counters[22], (unsigned long long)it_total);
+#endif
         atomicAdd(&K.counters[16], nr);                           // pending-child records written (64 B out, 64 B back in each)
     }
 }

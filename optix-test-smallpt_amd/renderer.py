@@ -177,7 +177,7 @@ class Renderer:
 
     def diag(self):
         """Phase timings / lane counters of the last launch of the instrumented build (variant bit 8)."""
-        arr = (C.c_uint64 * 15)()
+        arr = (C.c_uint64 * 24)()
         self._check(self._lib.spt_diag(self._h, C.byref(arr)))
         return [int(v) for v in arr]
 
