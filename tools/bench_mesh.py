@@ -47,6 +47,28 @@ def run(name, meshes, mats, w, h, samps, camera, rows, accel=0):
     return out
 
 
+def viewer_loop(name, meshes, mats, frames=200):
+    import torch
+    r = pkg.Renderer(0)
+    r.set_mesh_accel(pkg.ACCEL_BVH)
+    r.set_meshes(meshes, mats)
+    cam = pkg.smallpt_camera(1280, 720)
+    prog = pkg.ProgressiveRenderer(r, 1280, 720, 1, camera=cam)
+    for _ in range(10):
+        prog.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        prog.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    out = {"config": name, "accel": "bvh", "triangles": sum(m.triangle_count for m in meshes), "image": "1280x720", "spp": 4,
+           "frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3), "accum_nonzero": bool(float(prog.accum.abs().sum()) > 0)}
+    print(json.dumps(out), flush=True)
+    r.close()
+    return out
+
+
 def main():
     rows = []
     # the reference's live global table: Sphere(10, (50,40.8,81.6), 0, (.75,.25,.25), DIFF), Sphere(600, (50,681.6-.27,81.6), (1,1,1), 0, DIFF)
@@ -61,6 +83,8 @@ def main():
     big = [pkg.make_sphere_trimesh((50, 40.8, 81.6), 10.0, 256), pkg.make_sphere_trimesh((50, 681.6 - .27, 81.6), 600.0, 256)]
     rows.append(run("f4: the two spheres at subdivision 256 (2 x 262144 triangles), 1280x720, 4 spp, hierarchy (oracle rows skipped: "
                     "0.5 M triangles per ray on the CPU)", big, mats, 1280, 720, 1, None, [], accel=1))
+    rows.append(viewer_loop("f3 + f4: the viewer's render loop (ProgressiveRenderer, smallpt.cpp:895-942) on the shipped mesh scene, 1280x720, "
+                            "1 sample per jitter cell per frame, hierarchy", meshes, mats))
     meshes, mats = pkg.single_triangle_scene()
     rows.append(run("f4: SingleTriangleScene of main(), viewer camera", meshes, mats, 1280, 720, 1, pkg.pinhole_camera(), [300, 500]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
