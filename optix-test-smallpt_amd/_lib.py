@@ -47,6 +47,7 @@ SYMBOLS = {
     "spt_set_scene": (C.c_int, [_P, _P, C.c_uint32]),
     "spt_set_meshes": (C.c_int, [_P, C.POINTER(SptMesh), C.c_uint32, C.POINTER(SptMaterial)]),
     "spt_set_mesh_accel": (C.c_int, [_P, C.c_int]),
+    "spt_set_sphere_accel": (C.c_int, [_P, C.c_int]),
     "spt_trace_rays": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "spt_make_sphere_trimesh": (C.c_uint32, [C.c_float * 3, C.c_float, C.c_uint32, _P, _P, _P]),
     "spt_camera_smallpt": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(SptCamera)]),
@@ -70,6 +71,7 @@ SYMBOLS = {
 
 # test / tuning hooks declared in csrc/spt_internal.h (not part of the drop-in boundary)
 INTERNAL_SYMBOLS = {
+    "spt_selftest_sphere_bvh": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32 * 4), C.c_char_p, C.c_uint32]),
     "spt_selftest_bvh": (C.c_int, [C.POINTER(SptMesh), C.c_uint32, C.POINTER(C.c_uint32 * 4), C.c_char_p, C.c_uint32]),
     "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_diag": (C.c_int, [_P, C.POINTER(C.c_uint64 * 24)]),

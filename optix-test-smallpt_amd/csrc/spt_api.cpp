@@ -51,9 +51,16 @@ struct spt_ctx {
     float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
     size_t stack_cap = 0;          // in floats
     bool last_was_pool = false;
+    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
     float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
+    std::vector<float4> h_geom;      // host copy of the sphere table {centre, r*r} and the radii: its hierarchy is built on demand
+    std::vector<float> h_radius;
+    int sphere_accel = SPT_ACCEL_EXHAUSTIVE;
+    bool sbvh_ready = false;
+    float4* d_sbvh_nodes = nullptr; float4* d_sbvh_geom = nullptr; uint32_t* d_sbvh_index = nullptr; uint32_t* d_sbvh_always = nullptr;
+    uint32_t sbvh_nalways = 0, sbvh_depth = 0;
     std::vector<float4> h_tris;      // host copy of the triangle records: the hierarchy is built from it on demand
     int accel = SPT_ACCEL_EXHAUSTIVE;
     bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
@@ -166,6 +173,10 @@ void spt_destroy(spt_ctx* c)
     if (c->d_frame) (void)hipFree(c->d_frame);
     if (c->d_tris) (void)hipFree(c->d_tris);
     if (c->d_tri_index) (void)hipFree(c->d_tri_index);
+    if (c->d_sbvh_nodes) (void)hipFree(c->d_sbvh_nodes);
+    if (c->d_sbvh_geom) (void)hipFree(c->d_sbvh_geom);
+    if (c->d_sbvh_index) (void)hipFree(c->d_sbvh_index);
+    if (c->d_sbvh_always) (void)hipFree(c->d_sbvh_always);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_tris) (void)hipFree(c->d_bvh_tris);
     if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
@@ -192,6 +203,7 @@ int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
 // IEEE operations on the host, bit-identical to evaluating them per bounce:
 //   r*r (scene.cpp:133), pmax = fmaxf(color) (smallpt.cpp:177), color*(1/pmax) (smallpt.cpp:192).
 static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n);
+static int build_sphere_accel(spt_ctx* c);
 
 int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
 {
@@ -241,6 +253,10 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
     c->n = n;
     c->mesh_scene = false;
+    c->h_geom.assign(geom.begin(), geom.begin() + n);
+    c->h_radius.resize(n);
+    for (uint32_t i = 0; i < n; ++i) c->h_radius[i] = s[i].radius;
+    c->sbvh_ready = false;
     // The un-guarded square root (sqrt_rsq) in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
     // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
     c->needs_guard = false;
@@ -255,7 +271,63 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     for (uint32_t i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k)
             if (!(s[i].color[k] >= 0.f && s[i].color[k] <= 1.f) || !(std::fabs(s[i].emission[k]) <= 3e38f)) c->pool_ok = false;
+    return c->sphere_accel == SPT_ACCEL_BVH ? build_sphere_accel(c) : 0;
+}
+
+// Hierarchy over the current sphere table (spt_bvh.h build_sphere_bvh); the caller holds the C-boundary try block.
+static int build_sphere_accel(spt_ctx* c)
+{
+    spt::Bvh bvh;
+    spt::build_sphere_bvh(c->h_geom.data(), c->h_radius.data(), c->n, bvh);
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    auto upload = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
+        if (dptr) (void)hipFree(dptr);
+        dptr = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dptr), bytes ? bytes : 16);
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    SPT_HIP(c, upload(c->d_sbvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_sbvh_geom, bvh.tris.data(), bvh.tris.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_sbvh_index, bvh.index.data(), bvh.index.size() * sizeof(uint32_t)));
+    SPT_HIP(c, upload(c->d_sbvh_always, bvh.always.data(), bvh.always.size() * sizeof(uint32_t)));
+    c->sbvh_nalways = (uint32_t)bvh.always.size(); c->sbvh_depth = bvh.depth;
+    c->sbvh_ready = true;
     return 0;
+}
+
+int spt_set_sphere_accel(spt_ctx* c, int accel)
+{
+    if (!c) return 1;
+    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH) return c->fail("spt_set_sphere_accel: unknown mode %d", accel);
+    c->sphere_accel = accel;
+    if (accel != SPT_ACCEL_BVH || c->mesh_scene || !c->d_geom || c->sbvh_ready) return 0;
+    try {
+        return build_sphere_accel(c);
+    } catch (const std::exception& e) {
+        return c->fail("spt_set_sphere_accel: %s", e.what());
+    }
+}
+
+// Host-only self-test of the sphere hierarchy builder (no device call).  out4 = {nodes, leaves, depth, always-tested spheres}.
+int spt_selftest_sphere_bvh(const spt_sphere* s, uint32_t n, uint32_t* out4, char* why, uint32_t why_len)
+{
+    try {
+        std::vector<float4> geom(n);
+        std::vector<float> radius(n);
+        for (uint32_t i = 0; i < n; ++i) { geom[i] = make_float4(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius); radius[i] = s[i].radius; }
+        spt::Bvh bvh;
+        spt::build_sphere_bvh(geom.data(), radius.data(), n, bvh);
+        std::string reason;
+        const bool ok = spt::validate_sphere_bvh(geom.data(), radius.data(), n, bvh, reason);
+        if (out4) { out4[0] = (uint32_t)(bvh.nodes.size() / 4); out4[1] = bvh.leaves; out4[2] = bvh.depth; out4[3] = (uint32_t)bvh.always.size(); }
+        if (why && why_len) std::snprintf(why, why_len, "%s", reason.c_str());
+        return ok ? 0 : 2;
+    } catch (const std::exception& e) {
+        if (why && why_len) std::snprintf(why, why_len, "%s", e.what());
+        return 1;
+    }
 }
 
 // ---- triangle meshes (smallpt.cpp:427-473, scene.cpp:3-116) ----
@@ -604,8 +676,9 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
 
-    // ---- triangle-mesh scene (spt_mesh.hip): brute-force closest hit with the reference's triangle arithmetic ----
-    if (c->mesh_scene) {
+    // ---- triangle-mesh scene (spt_mesh.hip), or a sphere table too large for the pool kernel through its hierarchy ----
+    const bool sphere_bvh = !c->mesh_scene && c->sphere_accel == SPT_ACCEL_BVH && c->sbvh_ready && c->n > (uint32_t)spt_pool_max_spheres();
+    if (c->mesh_scene || sphere_bvh) {
         uint64_t blocks = (uint64_t)c->cu_count * (c->blocks_per_cu ? c->blocks_per_cu : 4u);
         const uint64_t needed = (ntasks + 255) / 256;
         if (blocks > needed) blocks = needed;
@@ -618,8 +691,14 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
             c->stack_cap = need_stack;
         }
         P.stack = c->d_stack;
-        P.n = 0; P.n_pad = 1; P.geom = nullptr; P.mat = nullptr;
-        const spt::MParams M = mesh_params(c);
+        spt::MParams M{};
+        if (sphere_bvh) {
+            M.bvh_nodes = c->d_sbvh_nodes; M.bvh_tris = c->d_sbvh_geom; M.bvh_index = c->d_sbvh_index;
+            M.always = c->d_sbvh_always; M.nalways = c->sbvh_nalways; M.sphere_mode = 1u;
+        } else {
+            P.n = 0; P.n_pad = 1; P.geom = nullptr; P.mat = nullptr;
+            M = mesh_params(c);
+        }
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));
         SPT_HIP(c, spt_mesh_launch(&P, &M, (uint32_t)blocks, st));
@@ -628,6 +707,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
         c->pending = true;
         c->last_was_pool = false;
+        c->last_kernel = sphere_bvh ? 3 : 2;
         c->last = spt_stats{};
         c->last.samples = npix * 4ull * samps;
         c->last.grid_blocks = (uint32_t)blocks;
@@ -669,6 +749,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
         c->pending = true;
         c->last_was_pool = true;
+        c->last_kernel = 1;
         c->last = spt_stats{};
         c->last.samples = npix * 4ull * samps;
         c->last.grid_blocks = (uint32_t)blocks;
@@ -676,6 +757,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         return 0;
     }
     c->last_was_pool = false;
+    c->last_kernel = 0;
 
     // launch geometry: a persistent grid that fills the chip; the task queue makes any size correct
     const int mat_lds = (c->n <= 256) ? 1 : 0;
@@ -848,7 +930,7 @@ int spt_set_watchdog(spt_ctx* c, double seconds)
     return 0;
 }
 
-int spt_last_kernel(spt_ctx* c) { return c ? (c->last_was_pool ? 1 : 0) : -1; }
+int spt_last_kernel(spt_ctx* c) { return c ? c->last_kernel : -1; }
 
 // Numerics self-test: runs device helper `op` (0 sqrt_fix, 2 sqrt_exact, 3 rcp_exact, 10 sqrt_rsq,
 // 4 double division by w, 5/6 sin/cos(2*pi*x), 7 rng_draw(bits(x))) over n host floats.

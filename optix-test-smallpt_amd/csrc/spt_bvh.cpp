@@ -53,17 +53,20 @@ Box padded_box(const float4* r)
 }
 
 // internal levels a subtree of `count` triangles needs when split at the median: leaf references end up that much deeper
-inline uint32_t levels_needed(uint32_t count)
+inline uint32_t levels_needed(uint32_t count, uint32_t leaf_max)
 {
-    uint32_t leaves = (count + kBvhLeafTris - 1) / kBvhLeafTris, l = 0;
+    uint32_t leaves = (count + leaf_max - 1) / leaf_max, l = 0;
     while ((1u << l) < leaves) ++l;
     return l;
 }
 
 struct Builder {
-    const float4* recs;
-    std::vector<Box> box;            // per global triangle
-    std::vector<float> cen;          // 3 per global triangle
+    const float4* recs;              // rec_f4 float4 per primitive, indexed by GLOBAL id
+    uint32_t rec_f4 = 3;
+    uint32_t leaf_max = kBvhLeafTris; // primitives per leaf (<= 7: three bits of the leaf reference)
+    std::vector<uint32_t> ids;       // global id of every primitive handed to the builder (empty = identity)
+    std::vector<Box> box;            // per primitive
+    std::vector<float> cen;          // 3 per primitive
     std::vector<uint32_t> order;     // permutation being partitioned
     Bvh* out;
 
@@ -72,12 +75,41 @@ struct Builder {
         const uint32_t first = (uint32_t)out->index.size();
         std::sort(order.begin() + lo, order.begin() + hi);               // ascending global index inside a leaf (tidy; ties are broken by index anyway)
         for (uint32_t i = lo; i < hi; ++i) {
-            const uint32_t g = order[i];
+            const uint32_t g = ids.empty() ? order[i] : ids[order[i]];
             out->index.push_back(g);
-            out->tris.push_back(recs[3 * (size_t)g]); out->tris.push_back(recs[3 * (size_t)g + 1]); out->tris.push_back(recs[3 * (size_t)g + 2]);
+            for (uint32_t k = 0; k < rec_f4; ++k) out->tris.push_back(recs[rec_f4 * (size_t)g + k]);
         }
         ++out->leaves;
         return ~(int32_t)((first << 3) | (hi - lo));
+    }
+
+    // whole hierarchy over the primitives whose boxes / centroids are set; the root is always node 0
+    void run()
+    {
+        const uint32_t n = (uint32_t)box.size();
+        if (n >= (1u << 28)) throw std::runtime_error("hierarchy: too many primitives for the leaf encoding");
+        order.resize(n);
+        std::iota(order.begin(), order.end(), 0u);
+        out->index.reserve(n); out->tris.reserve(rec_f4 * (size_t)n);
+        if (n <= leaf_max) {
+            // one leaf with everything, one empty leaf behind an inverted box
+            out->nodes.resize(4);
+            Box l = range_box(0, n), r; r.clear();
+            if (n == 0) l.clear();
+            const int32_t lr = leaf_ref(0, n), rr = ~(int32_t)0;
+            out->nodes[0] = make_float4(l.mn[0], l.mn[1], l.mn[2], l.mx[0]);
+            out->nodes[1] = make_float4(l.mx[1], l.mx[2], r.mn[0], r.mn[1]);
+            out->nodes[2] = make_float4(r.mn[2], r.mx[0], r.mx[1], r.mx[2]);
+            float4 refs = make_float4(0.f, 0.f, 0.f, 0.f);
+            std::memcpy(&refs.x, &lr, 4); std::memcpy(&refs.y, &rr, 4);
+            out->nodes[3] = refs;
+            out->depth = 1;
+        } else {
+            const int32_t root = build(0, n, 0);
+            if (root != 0) throw std::runtime_error("hierarchy: internal error (root is not node 0)");
+        }
+        if (out->tris.empty()) out->tris.resize(rec_f4, make_float4(0.f, 0.f, 0.f, 0.f));   // never read; keeps the device buffers non-empty
+        if (out->index.empty()) out->index.push_back(0u);
     }
 
     Box range_box(uint32_t lo, uint32_t hi) const
@@ -127,7 +159,7 @@ struct Builder {
                 return std::min(kBins - 1, (int)(((double)cen[3 * (size_t)g + a] - cmn[a]) * scale)) <= best_bin;
             });
             const uint32_t m = (uint32_t)(mid - order.begin());
-            if (m > lo && m < hi && levels_needed(m - lo) <= levels_left && levels_needed(hi - m) <= levels_left) return m;
+            if (m > lo && m < hi && levels_needed(m - lo, leaf_max) <= levels_left && levels_needed(hi - m, leaf_max) <= levels_left) return m;
         }
         // median along the widest centroid axis (or by index when all centroids coincide): depth stays logarithmic
         int a = 0;
@@ -144,7 +176,7 @@ struct Builder {
     int32_t build(uint32_t lo, uint32_t hi, uint32_t depth)
     {
         out->depth = std::max(out->depth, depth);
-        if (hi - lo <= kBvhLeafTris) return leaf_ref(lo, hi);
+        if (hi - lo <= leaf_max) return leaf_ref(lo, hi);
         if (depth >= kBvhMaxDepth) throw std::runtime_error("spt_set_mesh_accel: hierarchy depth bound violated");
         const uint32_t node = (uint32_t)(out->nodes.size() / 4);
         out->nodes.resize(out->nodes.size() + 4);
@@ -167,38 +199,65 @@ struct Builder {
 void build_bvh(const float4* recs, uint32_t ntris, Bvh& out)
 {
     out = Bvh{};
-    if (ntris >= (1u << 28)) throw std::runtime_error("spt_set_mesh_accel: too many triangles for the leaf encoding");
     Builder b;
-    b.recs = recs; b.out = &out;
-    b.box.resize(ntris); b.cen.resize(3 * (size_t)ntris); b.order.resize(ntris);
-    std::iota(b.order.begin(), b.order.end(), 0u);
+    b.recs = recs; b.rec_f4 = 3; b.out = &out;
+    b.box.resize(ntris); b.cen.resize(3 * (size_t)ntris);
     for (uint32_t g = 0; g < ntris; ++g) {
         b.box[g] = padded_box(recs + 3 * (size_t)g);
         for (int a = 0; a < 3; ++a) b.cen[3 * (size_t)g + a] = 0.5f * b.box[g].mn[a] + 0.5f * b.box[g].mx[a];
     }
-    out.index.reserve(ntris); out.tris.reserve(3 * (size_t)ntris);
-    if (ntris <= kBvhLeafTris) {
-        // the root is always a node: one leaf with everything, one empty leaf behind an inverted box
-        out.nodes.resize(4);
-        Box l = b.range_box(0, ntris), r; r.clear();
-        if (ntris == 0) l.clear();
-        const int32_t lr = b.leaf_ref(0, ntris), rr = ~(int32_t)0;
-        out.nodes[0] = make_float4(l.mn[0], l.mn[1], l.mn[2], l.mx[0]);
-        out.nodes[1] = make_float4(l.mx[1], l.mx[2], r.mn[0], r.mn[1]);
-        out.nodes[2] = make_float4(r.mn[2], r.mx[0], r.mx[1], r.mx[2]);
-        float4 refs = make_float4(0.f, 0.f, 0.f, 0.f);
-        std::memcpy(&refs.x, &lr, 4); std::memcpy(&refs.y, &rr, 4);
-        out.nodes[3] = refs;
-        out.depth = 1;
-    } else {
-        const int32_t root = b.build(0, ntris, 0);
-        if (root != 0) throw std::runtime_error("spt_set_mesh_accel: internal error (root is not node 0)");
-    }
-    if (out.tris.empty()) out.tris.resize(3, make_float4(0.f, 0.f, 0.f, 0.f));   // never read; keeps the device buffers non-empty
-    if (out.index.empty()) out.index.push_back(0u);
+    b.run();
 }
 
-bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why)
+// Box of a sphere, rounded outward, NOT padded: the traversal inflates node boxes per ray (spt_mesh.hip, closest_sphere_bvh)
+static Box sphere_box(const float4 g, float radius)
+{
+    const double r = std::fabs((double)radius);
+    if (!(std::isfinite(g.x) && std::isfinite(g.y) && std::isfinite(g.z) && std::isfinite(r)))
+        throw std::runtime_error("spt_set_sphere_accel: a sphere has non-finite centre or radius");
+    const double c[3] = {g.x, g.y, g.z};
+    Box b;
+    for (int a = 0; a < 3; ++a) { b.mn[a] = round_down(c[a] - r); b.mx[a] = round_up(c[a] + r); }
+    return b;
+}
+
+void build_sphere_bvh(const float4* geom, const float* radius, uint32_t n, Bvh& out)
+{
+    out = Bvh{};
+    // spheres far larger than the rest (the walls and the light of a Cornell box) would make every node box scene-sized:
+    // they are tested for every ray instead.  "Far larger" = more than 16 x the median radius; at most kBvhAlways of them.
+    std::vector<float> rs(n);
+    for (uint32_t i = 0; i < n; ++i) rs[i] = std::fabs(radius[i]);
+    std::vector<uint32_t> huge;
+    if (n > 0) {
+        std::vector<float> sorted(rs);
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const float cut = 16.0f * sorted[n / 2];
+        for (uint32_t i = 0; i < n; ++i) if (rs[i] > cut) huge.push_back(i);
+        if (huge.size() > kBvhAlways) {                                   // keep the largest ones
+            std::sort(huge.begin(), huge.end(), [&](uint32_t x, uint32_t y) { return rs[x] > rs[y] || (rs[x] == rs[y] && x < y); });
+            huge.resize(kBvhAlways);
+        }
+        std::sort(huge.begin(), huge.end());
+    }
+    out.always = huge;
+    Builder b;
+    b.recs = geom; b.rec_f4 = 1; b.out = &out;
+    size_t h = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (h < huge.size() && huge[h] == i) { ++h; continue; }
+        b.ids.push_back(i);
+        const Box bx = sphere_box(geom[i], radius[i]);
+        b.box.push_back(bx);
+        for (int a = 0; a < 3; ++a) b.cen.push_back(0.5f * bx.mn[a] + 0.5f * bx.mx[a]);
+    }
+    if (b.ids.empty()) b.ids.clear();
+    b.run();
+}
+
+// Shared structural walk; `expect[g]` = how often primitive g must be referenced (0 for the always-tested spheres).
+static bool validate_walk(const float4* recs, uint32_t rec_f4, uint32_t ntris, const std::vector<uint32_t>& expect,
+                          const std::vector<Box>& prim_box, const Bvh& bvh, std::string& why)
 {
     std::vector<uint32_t> seen(ntris, 0u);
     struct Item { int32_t ref; uint32_t depth; Box bound; };
@@ -211,17 +270,17 @@ bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::strin
         const Item it = stack.back(); stack.pop_back();
         if (it.ref < 0) {
             const uint32_t code = (uint32_t)~it.ref, first = code >> 3, cnt = code & 7u;
-            if (cnt > kBvhLeafTris) { why = "leaf count"; return false; }
+            if (cnt > 7u) { why = "leaf count"; return false; }
             if (it.depth > kBvhMaxDepth) { why = "leaf deeper than the bound"; return false; }
             for (uint32_t k = 0; k < cnt; ++k) {
                 if (first + k >= bvh.index.size()) { why = "leaf range"; return false; }
                 const uint32_t g = bvh.index[first + k];
                 if (g >= ntris) { why = "global index"; return false; }
                 ++seen[g];
-                if (std::memcmp(&bvh.tris[3 * (size_t)(first + k)], &recs[3 * (size_t)g], 48) != 0) { why = "leaf record differs from the source record"; return false; }
-                const Box pb = padded_box(recs + 3 * (size_t)g);
+                if (std::memcmp(&bvh.tris[rec_f4 * (size_t)(first + k)], &recs[rec_f4 * (size_t)g], 16 * rec_f4) != 0) { why = "leaf record differs from the source record"; return false; }
+                const Box& pb = prim_box[g];
                 for (int a = 0; a < 3; ++a)
-                    if (!(pb.mn[a] >= it.bound.mn[a] && pb.mx[a] <= it.bound.mx[a])) { why = "triangle outside its leaf's box"; return false; }
+                    if (!(pb.mn[a] >= it.bound.mn[a] && pb.mx[a] <= it.bound.mx[a])) { why = "primitive outside its leaf's box"; return false; }
             }
             continue;
         }
@@ -241,8 +300,28 @@ bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::strin
         stack.push_back({rr, it.depth + 1, r});
     }
     for (uint32_t g = 0; g < ntris; ++g)
-        if (seen[g] != 1u) { why = "triangle " + std::to_string(g) + " referenced " + std::to_string(seen[g]) + " times"; return false; }
+        if (seen[g] != expect[g]) { why = "primitive " + std::to_string(g) + " referenced " + std::to_string(seen[g]) + " times"; return false; }
     return true;
+}
+
+bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why)
+{
+    std::vector<Box> pb(ntris);
+    for (uint32_t g = 0; g < ntris; ++g) pb[g] = padded_box(recs + 3 * (size_t)g);
+    return validate_walk(recs, 3, ntris, std::vector<uint32_t>(ntris, 1u), pb, bvh, why);
+}
+
+bool validate_sphere_bvh(const float4* geom, const float* radius, uint32_t n, const Bvh& bvh, std::string& why)
+{
+    std::vector<Box> pb(n);
+    std::vector<uint32_t> expect(n, 1u);
+    for (uint32_t g = 0; g < n; ++g) pb[g] = sphere_box(geom[g], radius[g]);
+    if (bvh.always.size() > kBvhAlways) { why = "always-list too long"; return false; }
+    for (size_t k = 0; k < bvh.always.size(); ++k) {
+        if (bvh.always[k] >= n || (k && bvh.always[k] <= bvh.always[k - 1])) { why = "always-list not ascending / out of range"; return false; }
+        expect[bvh.always[k]] = 0u;
+    }
+    return validate_walk(geom, 1, n, expect, pb, bvh, why);
 }
 
 }  // namespace spt

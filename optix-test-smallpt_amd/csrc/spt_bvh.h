@@ -24,13 +24,15 @@
 namespace spt {
 
 constexpr uint32_t kBvhMaxDepth = 32;      // children of the root are at depth 1; a leaf reference sits at depth <= 32
-constexpr uint32_t kBvhLeafTris = 4;
+constexpr uint32_t kBvhLeafTris = 4;         // primitives per leaf (triangles or spheres)
+constexpr uint32_t kBvhAlways = 32;          // sphere hierarchies: at most this many outsized spheres are tested for every ray
 
 // Child reference: >= 0 = node index; < 0 = leaf, ~ref = (first leaf-order triangle << 3) | count (count 0 = empty).
 struct Bvh {
     std::vector<float4> nodes;        // 4 x float4 per node: {lmin.xyz, lmax.x} {lmax.yz, rmin.xy} {rmin.z, rmax.xyz} {left, right, 0, 0}
     std::vector<float4> tris;         // 3 x float4 per triangle in leaf order (the records of MParams::tris)
     std::vector<uint32_t> index;      // global (instance-major) triangle index of every leaf-order triangle
+    std::vector<uint32_t> always;     // sphere hierarchies: global indices (ascending) of the spheres kept out of the tree
     uint32_t depth = 0, leaves = 0;
 };
 
@@ -39,6 +41,13 @@ void build_bvh(const float4* recs, uint32_t ntris, Bvh& out);
 // Structural check used by the CPU tests: every triangle in exactly one leaf, every box contains its subtree's padded
 // triangles, depth bound respected.  Returns false and a reason on failure.
 bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why);
+
+// The same hierarchy over a sphere table (SPT_ACCEL_BVH of spt_set_sphere_accel): geom[i] = {centre, r*r}, radius[i] = r.
+// Node boxes are the spheres' own extents (no padding: closest_sphere_bvh inflates every box it tests by a bound on the
+// rounding error of intersectAnalytic for THAT ray, which is what makes the traversal provably exhaustive-equivalent);
+// `tris` holds one float4 {centre, r*r} per sphere in leaf order.
+void build_sphere_bvh(const float4* geom, const float* radius, uint32_t n, Bvh& out);
+bool validate_sphere_bvh(const float4* geom, const float* radius, uint32_t n, const Bvh& bvh, std::string& why);
 
 }  // namespace spt
 #endif

@@ -25,7 +25,8 @@ int  spt_diag(spt_ctx* ctx, unsigned long long* out24);
  * makes spt_sync fail instead of returning an incomplete image.  Tests set a few seconds so that a scheduling bug
  * cannot hang the GPU box. */
 int  spt_set_watchdog(spt_ctx* ctx, double seconds);
-/* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip).
+/* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip),
+ * 2 = mesh kernel (spt_mesh.hip, triangles), 3 = mesh kernel over a sphere hierarchy (spt_set_sphere_accel).
  * After a pool launch spt_diag returns out24[0..2] = batches per class (GEN, DIFF, REFR), [3..5] = lanes per class. */
 int  spt_last_kernel(spt_ctx* ctx);
 
@@ -50,6 +51,8 @@ int  spt_selftest_range(spt_ctx* ctx, int op, uint32_t first, uint32_t count, ui
  * the padded triangles below it and that no reference lies deeper than the 32-entry traversal stack allows.
  * out4 = {nodes, leaves, depth, triangles}; returns 0 = valid, 2 = invalid (reason in `why`), 1 = builder error. */
 int  spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, char* why, uint32_t why_len);
+/* The same for the sphere hierarchy of spt_set_sphere_accel; out4 = {nodes, leaves, depth, always-tested spheres}. */
+int  spt_selftest_sphere_bvh(const spt_sphere* spheres, uint32_t n, uint32_t* out4, char* why, uint32_t why_len);
 
 #ifdef __cplusplus
 }

@@ -150,7 +150,104 @@ __device__ __forceinline__ uint32_t closest_triangle_bvh(const MParams& M, uint3
     return near_tri;
 }
 
+// ---- sphere tables through a hierarchy (spt_set_sphere_accel; spt_bvh.h build_sphere_bvh) -----------------------------------
+// intersectAnalytic of one sphere record {c, r*r} on the integer keys of the sphere kernels (scene.cpp:129-140, smallpt.cpp:59-65):
+// key(t) = bits(t) - (bits(eps) + 1); returns the smaller of the two root keys (NaN roots give keys above every valid one).
+constexpr uint32_t kSphEpsBias = 0x38D1B717u + 1u;               // bits(1e-4f) + 1
+constexpr uint32_t kSphInfKey = 0x60AD78ECu - kSphEpsBias;       // key of 1e20f
+__device__ __forceinline__ uint32_t sphere_key(const float4 g, f3 o, f3 d)
+{
+    const f3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);                                  // :132
+    const float bb = dot(op, d);                                                        // :133
+    const float det = bb * bb - dot(op, op) + g.w;                                      // :133 (g.w = r*r)
+    const float sd = sqrt_exact(det);                                                   // :134 (NaN for det < 0: both keys lose)
+    const uint32_t key1 = __float_as_uint(bb - sd) - kSphEpsBias;                       // :135
+    const uint32_t key2 = __float_as_uint(bb + sd) - kSphEpsBias;
+    return key1 < key2 ? key1 : key2;
+}
+
+// Closest sphere by traversal.  EXHAUSTIVE-EQUIVALENT BY CONSTRUCTION, unlike the triangle hierarchy: intersectAnalytic divides
+// by nothing, so its rounding error is bounded.  With u = 2^-24, e = c - o and the reported t of a sphere, the point
+// p = o + t d satisfies | |p - c|^2 - r*r | <= 101 u (|e|^2 + r*r) (error budget of the ten operations):
+// p lies within sqrt(r*r + E) of c, E = 2^-16 (|e|^2 + r*r) taken with a 2.5x reserve.  A child box holds c +- r of its
+// spheres, so with D = the distance from o to the box's farthest corner (>= sqrt(|e|^2 + r*r) for every sphere inside) the box
+// inflated by pad = 2^-7 D contains p with half of the pad to spare (2^-8 D covers sqrt(E); the other half absorbs the
+// rounding of this slab test, ~3u D).  (One pad for the whole traversal from the root's extent was measured: fatter boxes,
+// 4-12 % slower.)  Hence a sphere whose reported key beats the final answer is never skipped: its box is
+// entered at a parameter <= its t <= the current nearest.  NaN from 0 * inf drops out of v_min/v_max (no constraint).
+__device__ __forceinline__ uint32_t closest_sphere_bvh(const KParams& K, const MParams& M, const float4* nodes, const float4* leaf_geom, const uint32_t* leaf_index,
+                                                    uint32_t* s_stack, bool active, f3 ro, f3 rd, float& t_out)
+{
+    uint32_t near_key = kSphInfKey, near_i = 0xFFFFFFFFu;
+    if (active) {
+        float tcut = 1e20f;
+        auto consider = [&](const float4 g, uint32_t index) {
+            const uint32_t key = sphere_key(g, ro, rd);
+            if (key < near_key || (key == near_key && index < near_i)) {       // ascending index + strict '<' of smallpt.cpp:61
+                if (key < kSphInfKey) { near_key = key; near_i = index; tcut = __uint_as_float(key + kSphEpsBias) * 1.0001f; }
+            }
+        };
+        for (uint32_t k = 0; k < M.nalways; ++k) { const uint32_t i = M.always[k]; consider(K.geom[i], i); }
+        const f3 iv = mk(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+        uint32_t sp = 0;
+        int cur = 0;
+        for (;;) {
+            if (cur >= 0) {
+                const float4* nd = nodes + 4 * (size_t)cur;
+                const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                // child boxes relative to the origin; farthest-corner distance; inflation
+                const float l0x = a.x - ro.x, l1x = a.w - ro.x, l0y = a.y - ro.y, l1y = b.x - ro.y, l0z = a.z - ro.z, l1z = b.y - ro.z;
+                const float r0x = b.z - ro.x, r1x = c.y - ro.x, r0y = b.w - ro.y, r1y = c.z - ro.y, r0z = c.x - ro.z, r1z = c.w - ro.z;
+                const float lmx = __builtin_fmaxf(__builtin_fabsf(l0x), __builtin_fabsf(l1x)), lmy = __builtin_fmaxf(__builtin_fabsf(l0y), __builtin_fabsf(l1y)),
+                            lmz = __builtin_fmaxf(__builtin_fabsf(l0z), __builtin_fabsf(l1z));
+                const float rmx = __builtin_fmaxf(__builtin_fabsf(r0x), __builtin_fabsf(r1x)), rmy = __builtin_fmaxf(__builtin_fabsf(r0y), __builtin_fabsf(r1y)),
+                            rmz = __builtin_fmaxf(__builtin_fabsf(r0z), __builtin_fabsf(r1z));
+                // 2^-7 D with D >= the Euclidean distance: the (1 ulp) v_sqrt_f32 of the sum of squares times 1.001 / 128
+                const float lp = __builtin_amdgcn_sqrtf(lmx * lmx + lmy * lmy + lmz * lmz) * (1.001f / 128.0f);
+                const float rp = __builtin_amdgcn_sqrtf(rmx * rmx + rmy * rmy + rmz * rmz) * (1.001f / 128.0f);
+                const float lx0 = (l0x - lp) * iv.x, lx1 = (l1x + lp) * iv.x, ly0 = (l0y - lp) * iv.y, ly1 = (l1y + lp) * iv.y, lz0 = (l0z - lp) * iv.z, lz1 = (l1z + lp) * iv.z;
+                const float rx0 = (r0x - rp) * iv.x, rx1 = (r1x + rp) * iv.x, ry0 = (r0y - rp) * iv.y, ry1 = (r1y + rp) * iv.y, rz0 = (r0z - rp) * iv.z, rz1 = (r1z + rp) * iv.z;
+                const float ln = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)), __builtin_fminf(lz0, lz1));
+                const float lf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)), __builtin_fmaxf(lz0, lz1));
+                const float rn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)), __builtin_fminf(rz0, rz1));
+                const float rf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)), __builtin_fmaxf(rz0, rz1));
+                // an empty child (inverted box: mn = +inf, mx = -inf) gives tn = +inf, tf = -inf (or NaN): never entered
+                const bool hl = (lf >= 0.f) & (ln <= lf) & (ln <= tcut);
+                const bool hr = (rf >= 0.f) & (rn <= rf) & (rn <= tcut);
+                const int lref = __float_as_int(d.x), rref = __float_as_int(d.y);
+                if (hl & hr) {
+                    const bool left_first = ln <= rn;
+                    s_stack[sp * kMeshBlock + threadIdx.x] = (uint32_t)(left_first ? rref : lref);
+                    ++sp;
+                    cur = left_first ? lref : rref;
+                    continue;
+                }
+                if (hl | hr) { cur = hl ? lref : rref; continue; }
+            } else {
+                const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = code & 7u;
+                for (uint32_t k = 0; k < cnt; ++k) consider(leaf_geom[first + k], leaf_index[first + k]);
+            }
+            if (sp == 0u) break;
+            --sp;
+            cur = (int)s_stack[sp * kMeshBlock + threadIdx.x];
+        }
+    }
+    t_out = __uint_as_float(near_key + kSphEpsBias);
+    return near_i;
+}
+
 struct MeshHit { float dist; uint32_t inst, tri; f3 x, n; float u, v; };
+
+// Sphere::makeHit(SphereHit) (scene.cpp:118-127): x = o + d t (scene.cpp:137), n = normalize(x - center)
+__device__ __forceinline__ MeshHit make_sphere_hit(const KParams& K, uint32_t i, float t, f3 ro, f3 rd)
+{
+    MeshHit h;
+    const float4 g = K.geom[i];
+    h.x = ro + rd * t;
+    h.n = normalize<true>(mk(h.x.x - g.x, h.x.y - g.y, h.x.z - g.z));
+    h.dist = t; h.inst = i; h.tri = 0u; h.u = 0.f; h.v = 0.f;
+    return h;
+}
 
 // makeHit(instId, mesh, meshHit), scene.cpp:73-93, for the winning triangle (u, v re-evaluated from its record)
 __device__ __forceinline__ MeshHit make_hit(const MParams& M, uint32_t tri, float t, f3 ro, f3 rd)
@@ -195,7 +292,9 @@ __global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const 
 // ---- path tracer over the mesh scene ------------------------------------------------------------------------------
 struct MPath { f3 o, d, w; uint32_t depth, branch, rbase; };
 
-template <bool BVH>
+// GEOM 0: triangles, exhaustive; 1: triangles through the hierarchy; 2: a sphere table through its hierarchy (staging a small
+// tree into LDS behind the stacks was measured: 30 % slower -- two workgroups per CU and conflicting per-lane ds_read_b128)
+template <int GEOM>
 __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const MParams M)
 {
     extern __shared__ float4 s_tile[];
@@ -280,20 +379,25 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
             ++s_gen;
             alive = true;
         }
-        if (!__syncthreads_or(alive ? 1 : 0)) break;           // no lane of the workgroup has work left
+        // exhaustive: the workgroup stages the triangle tiles together, so it leaves together; the traversals need no barrier and
+        // a wave must not wait for the slowest ray of its three neighbours every bounce
+        if (GEOM == 0) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
+        else if (__ballot(alive) == 0ull) break;
 
         // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
         float t;
-        const uint32_t tri = BVH ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
-                                 : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
+        const uint32_t tri = GEOM == 2 ? closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
+                           : GEOM == 1 ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
+                                       : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
         if (alive) {
             ++nbounce;
             if (tri == 0xFFFFFFFFu) {
                 alive = false;                                                   // smallpt.cpp:168 miss (D13)
             } else {
                 // ---- shadePaths, smallpt.cpp:170-263 under D2-D6, D18, D19 ----
-                const MeshHit h = make_hit(M, tri, t, p.o, p.d);
-                const float4 me = M.mats[3 * h.inst + 0], mc = M.mats[3 * h.inst + 1];
+                const MeshHit h = GEOM == 2 ? make_sphere_hit(K, tri, t, p.o, p.d) : make_hit(M, tri, t, p.o, p.d);
+                const float4* const mats = GEOM == 2 ? K.mat : M.mats;
+                const float4 me = mats[3 * h.inst + 0], mc = mats[3 * h.inst + 1];
                 const int refl = __float_as_int(me.w) & 3;
                 const f3 n = h.n;                                                // :173, un-normalised
                 const f3 nl = dot(n, p.d) < 0 ? n : neg(n);                      // :174 (D2)
@@ -301,7 +405,7 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
                 acc = acc + p.w * mk(me.x, me.y, me.z);                          // :179 (D4)
                 bool cont = true;
                 if (p.depth > 5) {                                               // :188 (D5)
-                    if (rng_draw(p.rbase, k1) < mc.w) { const float4 mf = M.mats[3 * h.inst + 2]; f = mk(mf.x, mf.y, mf.z); }
+                    if (rng_draw(p.rbase, k1) < mc.w) { const float4 mf = mats[3 * h.inst + 2]; f = mk(mf.x, mf.y, mf.z); }
                     else cont = false;
                 }
                 if (cont) {
@@ -383,8 +487,9 @@ extern "C" size_t spt_mesh_stack_floats(uint32_t blocks) { return (size_t)blocks
 
 extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream)
 {
-    if (M->bvh_nodes) hipLaunchKernelGGL(spt::meshkernel<true>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(1), stream, *K, *M);
-    else hipLaunchKernelGGL(spt::meshkernel<false>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(0), stream, *K, *M);
+    if (M->sphere_mode) hipLaunchKernelGGL(spt::meshkernel<2>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(1), stream, *K, *M);
+    else if (M->bvh_nodes) hipLaunchKernelGGL(spt::meshkernel<1>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(1), stream, *K, *M);
+    else hipLaunchKernelGGL(spt::meshkernel<0>, dim3(blocks), dim3(spt::kMeshBlock), spt_mesh_lds_bytes(0), stream, *K, *M);
     return hipGetLastError();
 }
 

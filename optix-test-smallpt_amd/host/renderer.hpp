@@ -77,6 +77,8 @@ public:
     // CPUIntersector (every triangle: SPT_ACCEL_EXHAUSTIVE, the default) or the OptixIntersector's acceleration structure
     // (rtpModelUpdate, smallpt.cpp:520-530: SPT_ACCEL_BVH); contract in include/smallpt_mi355x.h
     void setMeshAccel(int accel) { check(spt_set_mesh_accel(ctx_, accel)); }
+    // the same switch for sphere tables above 24 spheres (exhaustive-equivalent by construction, include/smallpt_mi355x.h)
+    void setSphereAccel(int accel) { check(spt_set_sphere_accel(ctx_, accel)); }
     std::vector<Hit> traceRays(const Ray* rays, size_t n)
     {
         std::vector<Hit> hits(n);

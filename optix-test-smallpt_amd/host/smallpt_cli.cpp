@@ -5,7 +5,7 @@
 //
 //   smallpt_mi355x [spp] [--scene file.json | shipped-meshes] [--size WxH] [--seed N] [--out image.ppm] [--device D]
 //                  [--dump-scene out.json] [--parse-only]
-//                  [--accel bvh|exhaustive]                    mesh scenes: OptixIntersector-style hierarchy or every triangle (default)
+//                  [--accel bvh|exhaustive]                    mesh scenes / sphere tables above 24: hierarchy or every primitive (default)
 //                  [--devices 0,1,...] [--self-exchange]      row bands over several GPUs + RCCL exchange (MultiRenderer)
 //   smallpt_mi355x [spp] --viewer [--frames N] [--request JSON] [--frames-after M] [--threaded] [--org x,y,z]
 //                  [--dump-raw accum.bin]                      main()'s progressive loop (smallpt.cpp:840-1005) without the
@@ -75,7 +75,7 @@ int main(int argc, char* argv[])
         Scene scene = scene_path.empty() ? cornell9() : (scene_path == "shipped-meshes" ? shipped_two_sphere_mesh_scene() : load_scene_file(scene_path));
         realize_meshes(scene);
         auto upload = [&](Renderer& rr) {          // spheres, or the Intersector seam for a mesh scene
-            if (scene.meshes.empty()) { rr.setScene(scene.spheres); return; }
+            if (scene.meshes.empty()) { rr.setSphereAccel(accel); rr.setScene(scene.spheres); return; }
             rr.setMeshAccel(accel);
             std::vector<TriMesh> ms; std::vector<Material> mats;
             for (const MeshInstance& m : scene.meshes) { ms.push_back(m.mesh); mats.push_back(m.material); }

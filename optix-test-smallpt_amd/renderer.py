@@ -106,6 +106,11 @@ class Renderer:
             mats[i].refl = int(refl)
         self._check(self._lib.spt_set_meshes(self._h, ms, len(meshes), mats))
 
+    def set_sphere_accel(self, accel):
+        """ACCEL_EXHAUSTIVE (default) or ACCEL_BVH for sphere tables above 24 spheres: a hierarchy that is exhaustive-equivalent by
+        construction (include/smallpt_mi355x.h)."""
+        self._check(self._lib.spt_set_sphere_accel(self._h, int(accel)))
+
     def set_mesh_accel(self, accel):
         """ACCEL_EXHAUSTIVE (default: every triangle, bit-identical to the reference's loops) or ACCEL_BVH (the role of the
         reference's OptiX Prime model, smallpt.cpp:475-603; contract in include/smallpt_mi355x.h)."""
@@ -158,8 +163,9 @@ class Renderer:
         self._check(self._lib.spt_set_watchdog(self._h, float(seconds)))
 
     def last_kernel(self):
-        """'pool' (spt_pool.hip, material-sorted) or 'mega' (spt_kernel.hip) for the last launch."""
-        return "pool" if self._lib.spt_last_kernel(self._h) == 1 else "mega"
+        """'pool' (spt_pool.hip, material-sorted), 'mega' (spt_kernel.hip), 'mesh' (spt_mesh.hip, triangles) or 'sbvh' (spt_mesh.hip over a
+        sphere hierarchy) for the last launch."""
+        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh"}[self._lib.spt_last_kernel(self._h)]
 
     def render_interleaved_device(self, out_tensor, w, h, block_rows, world, rank, samps_per_cell, seed=0,
                                   normalise=False, camera=None, stream=None):

@@ -34,6 +34,7 @@ while time.time() - t0 < budget:
     seed = int(rs.randint(0, 2**31)) * int(rs.choice([1, 2**20]))
     cam = None if rs.rand() < 0.6 else pkg.pinhole_camera(org=(50, 45, 250), vz=(0, 0, -1))
     norm = bool(rs.rand() < 0.5)
+    r.set_sphere_accel(pkg.ACCEL_BVH if rs.rand() < 0.5 else pkg.ACCEL_EXHAUSTIVE)     # tables above 24 spheres: hierarchy or megakernel
     r.set_scene(sc)
     img, st = r.render(w, h, samps, seed=seed, normalise=norm, camera=cam)
     ref, rst = orc.render(sc, w, h, samps, seed=seed, normalise=norm, camera=cam)
