@@ -143,8 +143,8 @@ int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const 
 int  spt_set_mesh_accel(spt_ctx* ctx, int accel);
 /* The same choice for SPHERE tables larger than the 24 the material-sorted kernel unrolls (smallpt.cpp:54-70 loops over all of
  * them).  Here the hierarchy is exhaustive-equivalent BY CONSTRUCTION: intersectAnalytic (scene.cpp:129-140) divides by nothing,
- * so the rounding error of a reported hit is bounded (101 u (|c - o|^2 + r^2) in |p - c|^2 - r^2) and every box is inflated, per
- * ray, by twice that bound before it may be skipped; spheres more than 16 x larger than the median
+ * so the error of a reported hit is bounded (101 u (|c - o|^2 + r^2) + | |d|^2 - 1 | t^2 in |p - c|^2 - r^2) and every box is
+ * inflated, per ray, by twice that bound before it may be skipped; spheres more than 16 x larger than the median
  * radius (walls, lights) stay outside the tree and are tested for every ray.  Default SPT_ACCEL_EXHAUSTIVE. */
 int  spt_set_sphere_accel(spt_ctx* ctx, int accel);
 /* Vector<Hit> Intersector::traceRays(const PathContrib*, size_t) (smallpt.cpp:460-470, :553-587): closest hit of n rays

@@ -167,14 +167,15 @@ __device__ __forceinline__ uint32_t sphere_key(const float4 g, f3 o, f3 d)
 }
 
 // Closest sphere by traversal.  EXHAUSTIVE-EQUIVALENT BY CONSTRUCTION, unlike the triangle hierarchy: intersectAnalytic divides
-// by nothing, so its rounding error is bounded.  With u = 2^-24, e = c - o and the reported t of a sphere, the point
-// p = o + t d satisfies | |p - c|^2 - r*r | <= 101 u (|e|^2 + r*r) (error budget of the ten operations):
-// p lies within sqrt(r*r + E) of c, E = 2^-16 (|e|^2 + r*r) taken with a 2.5x reserve.  A child box holds c +- r of its
-// spheres, so with D = the distance from o to the box's farthest corner (>= sqrt(|e|^2 + r*r) for every sphere inside) the box
-// inflated by pad = 2^-7 D contains p with half of the pad to spare (2^-8 D covers sqrt(E); the other half absorbs the
-// rounding of this slab test, ~3u D).  (One pad for the whole traversal from the root's extent was measured: fatter boxes,
-// 4-12 % slower.)  Hence a sphere whose reported key beats the final answer is never skipped: its box is
-// entered at a parameter <= its t <= the current nearest.  NaN from 0 * inf drops out of v_min/v_max (no constraint).
+// by nothing, so its rounding error is bounded.  With u = 2^-24, e = c - o, |d|^2 = 1 + eta and the reported t of a sphere, the
+// point p = o + t d satisfies | |p - c|^2 - r*r | <= 101 u (|e|^2 + r*r) + |eta| t^2 (error budget of the
+// ten operations; the eta term because the formula assumes a unit direction).  A child box holds c +- r of its spheres; with D =
+// the distance from o to the box's farthest corner (>= sqrt(|e|^2 + r*r) for every sphere inside, and t <= 2.1 D) the box
+// inflated by pad = (2^-7 + 2.1 sqrt(|eta| + 8u)) D contains p with 2^-8 D to spare: 2^-8 D covers the rounding budget
+// (sqrt of 2^-16 D^2, a 2.5x reserve on 101 u), 2.1 sqrt(|eta|) D the direction's length, the spare half absorbs the rounding
+// of this slab test (~3u D) and of the measured eta (8u).  Hence a sphere whose reported key beats the final answer is never
+// skipped: its box is entered at a parameter <= its t <= the current nearest.  NaN from 0 * inf drops out of v_min/v_max (no
+// constraint).  (One pad for the whole traversal from the root's extent was measured: fatter boxes, 4-12 % slower.)
 __device__ __forceinline__ uint32_t closest_sphere_bvh(const KParams& K, const MParams& M, const float4* nodes, const float4* leaf_geom, const uint32_t* leaf_index,
                                                     uint32_t* s_stack, bool active, f3 ro, f3 rd, float& t_out)
 {
@@ -189,6 +190,10 @@ __device__ __forceinline__ uint32_t closest_sphere_bvh(const KParams& K, const M
         };
         for (uint32_t k = 0; k < M.nalways; ++k) { const uint32_t i = M.always[k]; consider(K.geom[i], i); }
         const f3 iv = mk(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+        // inflation per unit of D for THIS ray: 2^-7 for the rounding budget, plus 2.1 sqrt(|eta|) for a direction whose squared
+        // length is 1 + eta (intersectAnalytic assumes 1; mirror reflections are not renormalised and drift over a long chain):
+        // the reported point then misses the sphere by |eta| t^2, t <= 2.1 D
+        const float kpad = (1.0f / 128.0f + 2.1f * __builtin_amdgcn_sqrtf(__builtin_fabsf(dot(rd, rd) - 1.0f) + 0x1p-21f)) * 1.001f;
         uint32_t sp = 0;
         int cur = 0;
         for (;;) {
@@ -202,9 +207,9 @@ __device__ __forceinline__ uint32_t closest_sphere_bvh(const KParams& K, const M
                             lmz = __builtin_fmaxf(__builtin_fabsf(l0z), __builtin_fabsf(l1z));
                 const float rmx = __builtin_fmaxf(__builtin_fabsf(r0x), __builtin_fabsf(r1x)), rmy = __builtin_fmaxf(__builtin_fabsf(r0y), __builtin_fabsf(r1y)),
                             rmz = __builtin_fmaxf(__builtin_fabsf(r0z), __builtin_fabsf(r1z));
-                // 2^-7 D with D >= the Euclidean distance: the (1 ulp) v_sqrt_f32 of the sum of squares times 1.001 / 128
-                const float lp = __builtin_amdgcn_sqrtf(lmx * lmx + lmy * lmy + lmz * lmz) * (1.001f / 128.0f);
-                const float rp = __builtin_amdgcn_sqrtf(rmx * rmx + rmy * rmy + rmz * rmz) * (1.001f / 128.0f);
+                // kpad D with D >= the Euclidean distance: the (1 ulp) v_sqrt_f32 of the sum of squares (the 1.001 sits in kpad)
+                const float lp = __builtin_amdgcn_sqrtf(lmx * lmx + lmy * lmy + lmz * lmz) * kpad;
+                const float rp = __builtin_amdgcn_sqrtf(rmx * rmx + rmy * rmy + rmz * rmz) * kpad;
                 const float lx0 = (l0x - lp) * iv.x, lx1 = (l1x + lp) * iv.x, ly0 = (l0y - lp) * iv.y, ly1 = (l1y + lp) * iv.y, lz0 = (l0z - lp) * iv.z, lz1 = (l1z + lp) * iv.z;
                 const float rx0 = (r0x - rp) * iv.x, rx1 = (r1x + rp) * iv.x, ry0 = (r0y - rp) * iv.y, ry1 = (r1y + rp) * iv.y, rz0 = (r0z - rp) * iv.z, rz1 = (r1z + rp) * iv.z;
                 const float ln = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)), __builtin_fminf(lz0, lz1));
