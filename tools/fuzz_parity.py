@@ -12,7 +12,7 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 r = pkg.Renderer(0)
 r.set_watchdog(60.0)
 kernels = {}
-t0 = time.time(); cases = 0; bad = 0
+t0 = time.time(); cases = 0; bad = 0; last_note = t0
 while time.time() - t0 < budget:
     n = int(rs.choice([1, 2, 3, 5, 9, 17, 24, 25, 40, 100, 257, 600]))
     rows = []
@@ -41,6 +41,9 @@ while time.time() - t0 < budget:
     ok = np.array_equal(img, ref, equal_nan=True) and st["bounces"] == rst["bounces"] and st["max_depth_kills"] == rst["max_depth_kills"]
     cases += 1
     kernels[r.last_kernel()] = kernels.get(r.last_kernel(), 0) + 1
+    if time.time() - last_note > 30:             # a silent GPU command is taken for hung after a few minutes
+        last_note = time.time()
+        print(f"... {cases} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     if not ok:
         bad += 1
         print("MISMATCH case", cases, dict(n=n, w=w, h=h, samps=samps, seed=seed, pinhole=cam is not None, norm=norm),
