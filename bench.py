@@ -248,7 +248,9 @@ def main():
                          "hbm_store_kernel": {"kernel": "spt::finalize", "ms": round(f_s * 1e3, 4),
                                               "achieved_GBps": round(count * W * (64 * nb + 12) / f_s / 1e9, 1),
                                               "bytes_per_pixel": 64 * nb + 12,
-                                              "peak_GBps": HBM_PEAK_GBPS}},
+                                              "peak_GBps": HBM_PEAK_GBPS,
+                                              "note": "reads the block sums the path kernel has just written (0.4 GB: Infinity-Cache "
+                                                      "assisted, not a pure HBM rate) and stores the 12 B/pixel image"}},
         }
         if world == 1 and not args.no_extras:
             # Outside the timed region: (1) the same step through spt_render, i.e. INCLUDING the framebuffer D2H copy into
