@@ -65,7 +65,7 @@ def d2h_inclusive(r, samps, steps):
             "note": "same step via spt_render: includes the D2H copy of the w*h*3 float image to pageable host memory"}
 
 
-def interactive(pkg, r, dev, frames=200):
+def interactive(pkg, r, dev, frames=600):
     """Render-thread loop of the viewer (smallpt.cpp:895-942) at the reference's window size: Cornell-9 seen by the
     pinhole Camera{vx,vy,vz,org,near=1} placed just inside the box's open front (the smallpt eye point lies outside the
     front-wall sphere; cpuRender pushes its rays 140 units forward, sampleRay does not), 1 sample per jitter cell per frame."""
@@ -257,7 +257,7 @@ def main():
             # host memory ("kernel + framebuffer D2H/gather"); never `value`, reported beside it.
             # (2) the reference's live use (smallpt.cpp:844-846,922): 1280x720, 1 sample per jitter cell per frame,
             # pinhole Camera + box-in-cell sampling, device-resident accumulation -- frames/s of the render-thread loop.
-            out["d2h_inclusive"] = d2h_inclusive(r, samps, max(1, min(3, args.steps)))
+            out["d2h_inclusive"] = d2h_inclusive(r, samps, max(1, min(10, args.steps)))
             out["interactive"] = interactive(pkg, r, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
