@@ -55,6 +55,7 @@ struct spt_ctx {
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
     float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
+    float* d_trace_rays = nullptr; float* d_trace_hits = nullptr; uint64_t trace_cap = 0;   // spt_trace_rays staging (rays)
     std::vector<float4> h_geom;      // host copy of the sphere table {centre, r*r} and the radii: its hierarchy is built on demand
     std::vector<float> h_radius;
     int sphere_accel = SPT_ACCEL_EXHAUSTIVE;
@@ -173,6 +174,8 @@ void spt_destroy(spt_ctx* c)
     if (c->d_frame) (void)hipFree(c->d_frame);
     if (c->d_tris) (void)hipFree(c->d_tris);
     if (c->d_tri_index) (void)hipFree(c->d_tri_index);
+    if (c->d_trace_rays) (void)hipFree(c->d_trace_rays);
+    if (c->d_trace_hits) (void)hipFree(c->d_trace_hits);
     if (c->d_sbvh_nodes) (void)hipFree(c->d_sbvh_nodes);
     if (c->d_sbvh_geom) (void)hipFree(c->d_sbvh_geom);
     if (c->d_sbvh_index) (void)hipFree(c->d_sbvh_index);
@@ -541,15 +544,23 @@ int spt_trace_rays(spt_ctx* c, const spt_ray* rays, uint64_t n, spt_hit* hits)
     static_assert(sizeof(spt_ray) == 24 && sizeof(spt_hit) == 44, "Ray / Hit layouts of scene.h");
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) { SPT_HIP(c, hipEventSynchronize(c->ev_stop)); }
-    float *d_rays = nullptr, *d_hits = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(spt_ray));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_hits), n * sizeof(spt_hit));
+    // ray / hit staging buffers are kept between calls (traceRays is called once per bounce by the reference's render loop)
+    hipError_t e = hipSuccess;
+    if (n > c->trace_cap) {
+        if (c->d_trace_rays) (void)hipFree(c->d_trace_rays);
+        if (c->d_trace_hits) (void)hipFree(c->d_trace_hits);
+        c->d_trace_rays = c->d_trace_hits = nullptr; c->trace_cap = 0;
+        e = hipMalloc(reinterpret_cast<void**>(&c->d_trace_rays), n * sizeof(spt_ray));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_trace_hits), n * sizeof(spt_hit));
+        if (e == hipSuccess) c->trace_cap = n;
+    }
+    float* const d_rays = c->d_trace_rays;
+    float* const d_hits = c->d_trace_hits;
     if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * sizeof(spt_ray), hipMemcpyHostToDevice, c->stream);
     const spt::MParams M = mesh_params(c);
     if (e == hipSuccess) e = spt_mesh_trace_rays(&M, d_rays, n, d_hits, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(spt_hit), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_rays); (void)hipFree(d_hits);
     if (e != hipSuccess) return c->fail("spt_trace_rays: %s", hipGetErrorString(e));
     return 0;
 }
