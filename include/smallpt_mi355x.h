@@ -141,11 +141,18 @@ int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const 
 #define SPT_ACCEL_EXHAUSTIVE 0
 #define SPT_ACCEL_BVH        1
 int  spt_set_mesh_accel(spt_ctx* ctx, int accel);
-/* The same choice for SPHERE tables larger than the 24 the material-sorted kernel unrolls (smallpt.cpp:54-70 loops over all of
- * them).  Here the hierarchy is exhaustive-equivalent BY CONSTRUCTION: intersectAnalytic (scene.cpp:129-140) divides by nothing,
- * so the error of a reported hit is bounded (101 u (|c - o|^2 + r^2) + | |d|^2 - 1 | t^2 in |p - c|^2 - r^2) and every box is
- * inflated, per ray, by twice that bound before it may be skipped; spheres more than 16 x larger than the median
- * radius (walls, lights) stay outside the tree and are tested for every ray.  Default SPT_ACCEL_EXHAUSTIVE. */
+/* How the closest hit of a SPHERE table larger than the 24 the material-sorted kernel unrolls is found (smallpt.cpp:54-70 loops
+ * over all of them).  Every mode returns the exhaustive loop's hit for every ray -- same intersectAnalytic arithmetic
+ * (scene.cpp:129-140) on the spheres it tests, same selection (smallest t > eps, lowest index among equal t) -- and the
+ * structures are exhaustive-equivalent BY CONSTRUCTION: intersectAnalytic divides by nothing, so the error of a reported hit is
+ * bounded (101 u (|c - o|^2 + r^2) + | |d|^2 - 1 | t^2 in |p - c|^2 - r^2) and no sphere is skipped unless it misses the ray by
+ * more than that bound (csrc/spt_grid.h).
+ *   SPT_ACCEL_GRID (default): a uniform grid held in LDS; spheres more than 16 x the median radius (walls, lights) are tested
+ *     for every ray, rays outside the error bound's precondition take the exhaustive loop.  Scenes that do not qualify (<= 24
+ *     spheres, degenerate radii / coordinates, tables beyond the LDS) run the exhaustive kernels as before.
+ *   SPT_ACCEL_BVH: a bounding-volume hierarchy with per-ray inflated boxes (round 2).
+ *   SPT_ACCEL_EXHAUSTIVE: every sphere for every ray. */
+#define SPT_ACCEL_GRID       2
 int  spt_set_sphere_accel(spt_ctx* ctx, int accel);
 /* Vector<Hit> Intersector::traceRays(const PathContrib*, size_t) (smallpt.cpp:460-470, :553-587): closest hit of n rays
  * against the current mesh scene; host buffers in and out like the reference's RTP_BUFFER_TYPE_HOST queries (:571-575). */

@@ -72,6 +72,7 @@ SYMBOLS = {
 # test / tuning hooks declared in csrc/spt_internal.h (not part of the drop-in boundary)
 INTERNAL_SYMBOLS = {
     "spt_selftest_sphere_bvh": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32 * 4), C.c_char_p, C.c_uint32]),
+    "spt_selftest_sphere_grid": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_char_p, C.c_uint32]),
     "spt_selftest_bvh": (C.c_int, [C.POINTER(SptMesh), C.c_uint32, C.POINTER(C.c_uint32 * 4), C.c_char_p, C.c_uint32]),
     "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_diag": (C.c_int, [_P, C.POINTER(C.c_uint64 * 24)]),

@@ -3,6 +3,7 @@
 #include "../../include/smallpt_mi355x.h"
 #include "spt_internal.h"
 #include "spt_bvh.h"
+#include "spt_grid.h"
 #include "spt_kernel.h"
 
 #include <chrono>
@@ -51,14 +52,19 @@ struct spt_ctx {
     float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
     size_t stack_cap = 0;          // in floats
     bool last_was_pool = false;
-    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy
+    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy, 4 grid kernel
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
     float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
     float* d_trace_rays = nullptr; float* d_trace_hits = nullptr; uint64_t trace_cap = 0;   // spt_trace_rays staging (rays)
     std::vector<float4> h_geom;      // host copy of the sphere table {centre, r*r} and the radii: its hierarchy is built on demand
     std::vector<float> h_radius;
-    int sphere_accel = SPT_ACCEL_EXHAUSTIVE;
+    int sphere_accel = SPT_ACCEL_GRID;
+    // uniform grid over the sphere table (spt_grid.h): built in spt_set_scene for tables above the pool kernel's limit
+    bool grid_ready = false;         // the tables below belong to the current sphere scene and the scene qualifies
+    spt::GridParams grid{};
+    uint32_t* d_grid_cells = nullptr; uint16_t* d_grid_refs = nullptr; uint32_t* d_grid_always = nullptr;
+    std::string grid_why;            // why the current scene does not run on the grid kernel
     bool sbvh_ready = false;
     float4* d_sbvh_nodes = nullptr; float4* d_sbvh_geom = nullptr; uint32_t* d_sbvh_index = nullptr; uint32_t* d_sbvh_always = nullptr;
     uint32_t sbvh_nalways = 0, sbvh_depth = 0;
@@ -176,6 +182,9 @@ void spt_destroy(spt_ctx* c)
     if (c->d_tri_index) (void)hipFree(c->d_tri_index);
     if (c->d_trace_rays) (void)hipFree(c->d_trace_rays);
     if (c->d_trace_hits) (void)hipFree(c->d_trace_hits);
+    if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
+    if (c->d_grid_refs) (void)hipFree(c->d_grid_refs);
+    if (c->d_grid_always) (void)hipFree(c->d_grid_always);
     if (c->d_sbvh_nodes) (void)hipFree(c->d_sbvh_nodes);
     if (c->d_sbvh_geom) (void)hipFree(c->d_sbvh_geom);
     if (c->d_sbvh_index) (void)hipFree(c->d_sbvh_index);
@@ -207,6 +216,7 @@ int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
 //   r*r (scene.cpp:133), pmax = fmaxf(color) (smallpt.cpp:177), color*(1/pmax) (smallpt.cpp:192).
 static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n);
 static int build_sphere_accel(spt_ctx* c);
+static int build_sphere_grid_tables(spt_ctx* c);
 
 int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
 {
@@ -260,6 +270,7 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     c->h_radius.resize(n);
     for (uint32_t i = 0; i < n; ++i) c->h_radius[i] = s[i].radius;
     c->sbvh_ready = false;
+    c->grid_ready = false;
     // The un-guarded square root (sqrt_rsq) in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
     // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
     c->needs_guard = false;
@@ -274,7 +285,41 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     for (uint32_t i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k)
             if (!(s[i].color[k] >= 0.f && s[i].color[k] <= 1.f) || !(std::fabs(s[i].emission[k]) <= 3e38f)) c->pool_ok = false;
-    return c->sphere_accel == SPT_ACCEL_BVH ? build_sphere_accel(c) : 0;
+    if (c->sphere_accel == SPT_ACCEL_BVH) return build_sphere_accel(c);
+    return c->sphere_accel == SPT_ACCEL_GRID ? build_sphere_grid_tables(c) : 0;
+}
+
+// LDS the grid kernel may spend on cell headers + references + the always-list, beside the 16-byte sphere records (one workgroup per CU)
+static size_t grid_table_budget(uint32_t n) { return (size_t)150 * 1024 - (size_t)(n ? n : 1u) * 16u; }
+
+// Uniform grid over the current sphere table (spt_grid.h); the caller holds the C-boundary try block.  Tables the pool kernel
+// takes, scenes that need the range-guarded square root and tables that do not fit the LDS keep the other kernels (grid_why says which).
+static int build_sphere_grid_tables(spt_ctx* c)
+{
+    c->grid_ready = false;
+    if (c->n <= (uint32_t)spt_pool_max_spheres()) { c->grid_why = "table small enough for the unrolled closest hit"; return 0; }
+    if (c->needs_guard) { c->grid_why = "scene needs the range-guarded square root"; return 0; }
+    if ((size_t)c->n * 16u + 8192u > (size_t)150 * 1024) { c->grid_why = "sphere records alone exceed the LDS"; return 0; }
+    spt::SphereGrid g;
+    const uint32_t dsel = (c->variant >> 24) & 0xFFu;
+    spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 8.0, grid_table_budget(c->n), g);
+    if (!g.usable) { c->grid_why = g.why; return 0; }
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    auto upload = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
+        if (dptr) (void)hipFree(dptr);
+        dptr = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dptr), bytes ? bytes : 16);
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    SPT_HIP(c, upload(c->d_grid_cells, g.cells.data(), g.cells.size() * sizeof(uint32_t)));
+    SPT_HIP(c, upload(c->d_grid_refs, g.refs.data(), g.refs.size() * sizeof(uint16_t)));
+    SPT_HIP(c, upload(c->d_grid_always, g.always.data(), g.always.size() * sizeof(uint32_t)));
+    c->grid = g.P;
+    c->grid_why.clear();
+    c->grid_ready = true;
+    return 0;
 }
 
 // Hierarchy over the current sphere table (spt_bvh.h build_sphere_bvh); the caller holds the C-boundary try block.
@@ -303,13 +348,37 @@ static int build_sphere_accel(spt_ctx* c)
 int spt_set_sphere_accel(spt_ctx* c, int accel)
 {
     if (!c) return 1;
-    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH) return c->fail("spt_set_sphere_accel: unknown mode %d", accel);
+    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH && accel != SPT_ACCEL_GRID) return c->fail("spt_set_sphere_accel: unknown mode %d", accel);
     c->sphere_accel = accel;
-    if (accel != SPT_ACCEL_BVH || c->mesh_scene || !c->d_geom || c->sbvh_ready) return 0;
+    if (accel == SPT_ACCEL_EXHAUSTIVE || c->mesh_scene || !c->d_geom) return 0;
     try {
-        return build_sphere_accel(c);
+        if (accel == SPT_ACCEL_BVH) return c->sbvh_ready ? 0 : build_sphere_accel(c);
+        return c->grid_ready ? 0 : build_sphere_grid_tables(c);
     } catch (const std::exception& e) {
         return c->fail("spt_set_sphere_accel: %s", e.what());
+    }
+}
+
+// Host-only self-test of the grid builder (no device call).  out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, 0}.
+int spt_selftest_sphere_grid(const spt_sphere* s, uint32_t n, uint32_t cells_per_sphere, uint32_t* out8, char* why, uint32_t why_len)
+{
+    try {
+        std::vector<float4> geom(n);
+        std::vector<float> radius(n);
+        for (uint32_t i = 0; i < n; ++i) { geom[i] = make_float4(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius); radius[i] = s[i].radius; }
+        spt::SphereGrid g;
+        spt::build_sphere_grid(geom.data(), radius.data(), n, cells_per_sphere ? (double)cells_per_sphere : 8.0, grid_table_budget(n), g);
+        std::string reason = g.why;
+        const bool ok = g.usable && spt::validate_sphere_grid(geom.data(), radius.data(), n, g, reason);
+        if (out8) {
+            out8[0] = (uint32_t)g.P.dim[0]; out8[1] = (uint32_t)g.P.dim[1]; out8[2] = (uint32_t)g.P.dim[2]; out8[3] = g.P.nrefs;
+            out8[4] = (uint32_t)g.always.size(); out8[5] = (uint32_t)g.lds_bytes(); out8[6] = g.usable ? 1u : 0u; out8[7] = 0u;
+        }
+        if (why && why_len) std::snprintf(why, why_len, "%s", reason.c_str());
+        return ok ? 0 : 2;
+    } catch (const std::exception& e) {
+        if (why && why_len) std::snprintf(why, why_len, "%s", e.what());
+        return 1;
     }
 }
 
@@ -687,6 +756,35 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     const float scale = 1.0f / (float)(4u * samps);   // smallpt.cpp:360 operator/=(float3, float)
 
+    // ---- large sphere table through its uniform grid (spt_grid.hip): the default above the pool kernel's limit ----
+    if (!c->mesh_scene && c->sphere_accel == SPT_ACCEL_GRID && c->grid_ready && cam_big <= 1e15f && !(c->variant & 0x400u)) {
+        const uint32_t blocks = (uint32_t)c->cu_count * (c->blocks_per_cu ? c->blocks_per_cu : 1u);   // one 1024-thread workgroup per CU shares the LDS tables
+        const size_t need_stack = spt_grid_stack_floats(blocks);
+        if (need_stack > c->stack_cap) {
+            if (c->d_stack) (void)hipFree(c->d_stack);
+            c->d_stack = nullptr; c->stack_cap = 0;
+            SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_stack), need_stack * sizeof(float)));
+            c->stack_cap = need_stack;
+        }
+        P.stack = c->d_stack;
+        P.watchdog_ticks = c->watchdog_ticks;
+        const uint32_t lsel = (c->variant >> 16) & 0xFFu;
+        SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
+        SPT_HIP(c, hipEventRecord(c->ev_start, st));
+        SPT_HIP(c, spt_grid_launch(&P, &c->grid, c->d_grid_cells, c->d_grid_refs, c->d_grid_always, blocks, lsel ? lsel - 1u : 16u, st));
+        SPT_HIP(c, hipEventRecord(c->ev_mid, st));
+        SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
+        SPT_HIP(c, hipEventRecord(c->ev_stop, st));
+        c->pending = true;
+        c->last_was_pool = false;
+        c->last_kernel = 4;
+        c->last = spt_stats{};
+        c->last.samples = npix * 4ull * samps;
+        c->last.grid_blocks = blocks;
+        c->last.block_threads = (uint32_t)spt_grid_block_threads();
+        return 0;
+    }
+
     // ---- triangle-mesh scene (spt_mesh.hip), or a sphere table too large for the pool kernel through its hierarchy ----
     const bool sphere_bvh = !c->mesh_scene && c->sphere_accel == SPT_ACCEL_BVH && c->sbvh_ready && c->n > (uint32_t)spt_pool_max_spheres();
     if (c->mesh_scene || sphere_bvh) {
@@ -826,7 +924,7 @@ int spt_sync(spt_ctx* c, spt_stats* stats)
         c->last.max_depth_kills = ctr[1];
         if (c->variant & 0x100u) SPT_HIP(c, hipMemcpy(c->diag, c->d_counters + 2, sizeof c->diag, hipMemcpyDeviceToHost));
         c->pending = false;
-        if (c->last_was_pool) {
+        if (c->last_was_pool || c->last_kernel == 4) {
             SPT_HIP(c, hipMemcpy(c->pool_stats, c->d_counters + 2, sizeof c->pool_stats, hipMemcpyDeviceToHost));
             if (c->pool_stats[6] != 0)
                 return c->fail("spt_sync: %llu waves hit the kernel watchdog; the image is incomplete", c->pool_stats[6]);
@@ -926,7 +1024,7 @@ int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
 int spt_diag(spt_ctx* c, unsigned long long* out24)
 {
     if (!c || !out24) return 1;
-    if (c->last_was_pool) {
+    if (c->last_was_pool || c->last_kernel == 4) {
         std::memcpy(out24, c->pool_stats, sizeof c->pool_stats);
         return 0;
     }

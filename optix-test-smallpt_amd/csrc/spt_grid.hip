@@ -1,0 +1,387 @@
+// spt_grid.hip -- persistent path-tracing kernel for LARGE sphere tables on gfx950 (MI355X): the closest hit of
+// intersectGlobalSpheres (smallpt.cpp:54-70 over scene.cpp:129-140) goes through a uniform grid that is exhaustive-equivalent by
+// construction (spt_grid.h), everything else -- shadePaths (smallpt.cpp:154-267), camera rays, RNG (D7), accumulation order (D9),
+// sin/cos (D17), depth cap (D18), zero-weight cut (D19) -- is the arithmetic of spt_kernel.hip / the oracle, bit for bit.
+//
+//   * ONE workgroup of 1024 threads per CU shares one LDS copy of the whole structure: sphere records {c, r*r} (16 B), cell headers
+//     (4 B: first reference << 13 | count, a one-cell border of sentinels), 16-bit sphere references, the always-tested list.
+//     Config 5 (1024 spheres): 16 + 55 + 11 KB of the CU's 160 KB; every lookup of the walk is an LDS read, none goes to memory.
+//   * a lane owns a path (registers) and is in one of four states: NONE (needs a camera ray / a pending glass child / a task),
+//     FRESH (has a new ray), WALK (inside the grid), HIT (closest hit known, waits for shading).  The wave runs the phases
+//     regenerate -> begin walks -> walk -> shade in a loop; inside the walk phase a lane either TESTS the next sphere of its cell
+//     or STEPS to the next cell, and each iteration runs whichever of the two more lanes want.  The walk phase is left as soon as
+//     fewer lanes are still walking than wait for shading / regeneration: the stragglers keep their walk state and continue in
+//     the next round together with the rays the others have produced meanwhile, so neither a long ray nor a crowded cell holds
+//     the other 63 lanes for long.
+//   * rays the grid may not take (origin too far from the box for the error bound, direction whose squared length has drifted from
+//     1: spt_grid.h (1)) run the exhaustive loop in place; spheres more than 16 x the median radius (the walls and the light of a
+//     Cornell box) are tested for every ray before the walk, which also bounds it.
+#include "spt_device.h"
+#include "spt_grid.h"
+#include "spt_kernel.h"
+
+namespace spt {
+
+constexpr int kGridBlock = 1024;
+constexpr uint32_t kGEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) + 1
+constexpr uint32_t kGInfKey = 0x60AD78ECu - kGEpsBias;           // key of 1e20f (maths.h:16)
+constexpr int kGChunk = 64;                                      // task ids fetched from the global queue per atomic
+
+enum : uint32_t { M_NONE = 0, M_FRESH = 1, M_WALK = 2, M_HIT = 3 };
+
+__device__ __forceinline__ uint32_t lane_id_g() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// intersectAnalytic of one sphere record {c, r*r} on integer keys (scene.cpp:129-140, smallpt.cpp:59-65): key(t) = bits(t) - (bits(eps) + 1),
+// "t > eps && t < nearest" is one unsigned compare; det < 0 gives NaN roots whose keys lie above every valid one.
+__device__ __forceinline__ uint32_t sphere_key_g(const float4 g, f3 o, f3 d)
+{
+    const f3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);                                  // :132
+    const float bb = dot(op, d);                                                        // :133
+    const float det = bb * bb - dot(op, op) + g.w;                                      // :133 (g.w = r*r)
+    const float sd = sqrt_rsq(det);                                                     // :134
+    const uint32_t key1 = __float_as_uint(bb - sd) - kGEpsBias;                         // :135
+    const uint32_t key2 = __float_as_uint(bb + sd) - kGEpsBias;
+    return key1 < key2 ? key1 : key2;
+}
+
+struct GPath { f3 o, d, w; uint32_t depth, branch, rbase; };
+
+__global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
+                                                         const uint16_t* __restrict__ g_refs, const uint32_t* __restrict__ g_always, uint32_t leave_q)
+{
+    extern __shared__ float4 s_geom[];                           // n sphere records, then the grid tables
+    uint32_t* const s_cells = reinterpret_cast<uint32_t*>(s_geom + (G.n ? G.n : 1u));
+    uint32_t* const s_always = s_cells + G.ncells;
+    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_always + G.nalways);
+    for (uint32_t i = threadIdx.x; i < G.n; i += kGridBlock) s_geom[i] = K.geom[i];
+    for (uint32_t i = threadIdx.x; i < G.ncells; i += kGridBlock) s_cells[i] = g_cells[i];
+    for (uint32_t i = threadIdx.x; i < G.nalways; i += kGridBlock) s_always[i] = g_always[i];
+    for (uint32_t i = threadIdx.x; i < G.nrefs; i += kGridBlock) s_refs[i] = g_refs[i];
+    __syncthreads();
+
+    const uint32_t lane = lane_id_g();
+    const uint32_t gthread = blockIdx.x * kGridBlock + threadIdx.x;
+    float* const gstack = K.stack + (size_t)gthread * (3 * 12);  // 3 pending transmitted children x 12 words per thread
+    const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
+    const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
+    const f3 cam_cx = mk(K.cam_cx[0], K.cam_cx[1], K.cam_cx[2]);
+    const f3 cam_cy = mk(K.cam_cy[0], K.cam_cy[1], K.cam_cy[2]);
+
+    // per-lane state
+    uint32_t mode = M_NONE;
+    bool task_valid = false, queue_empty = false;
+    uint32_t task = 0, sp = 0, s_gen = 0, s_end = 0, px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
+    GPath p{mk(0, 0, 0), mk(0, 0, 1), mk(0, 0, 0), 0u, 0u, 0u};
+    f3 acc = mk(0, 0, 0);
+    GridWalk w{};
+    uint32_t cur = 0, end = 0;                                   // references of the current cell still to test; cur == end outside the walk
+    uint32_t near_key = kGInfKey, near_i = 0xFFFFFFFFu;
+    uint32_t nbounce = 0, nkill = 0;
+    uint32_t chunk_next = 0, chunk_end = 0;                      // wave-uniform: this wave's private range of task ids
+    // statistics (wave-uniform counters, lane 0 reports)
+    unsigned long long n_steps = 0, n_tests = 0, n_step_iters = 0, n_test_iters = 0, n_fallback = 0, n_rounds = 0, n_shade_lanes = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    bool timed_out = false;
+
+    for (;;) {
+        ++n_rounds;
+        if ((n_rounds & 63ull) == 0ull && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
+        // ================= A: regeneration (smallpt.cpp:304-340, :252 pop) =================
+        if (mode == M_NONE && sp > 0) {                          // pending transmitted child of the lane's current sample
+            --sp;
+            const float* e = gstack + sp * 12;
+            p.o = mk(e[0], e[1], e[2]); p.d = mk(e[3], e[4], e[5]); p.w = mk(e[6], e[7], e[8]);
+            const uint32_t db = __float_as_uint(e[9]);
+            p.depth = db & 0xFFFFu; p.branch = db >> 16;
+            p.rbase = rng_base(k0, p.branch, p.depth);
+            mode = M_FRESH;
+        }
+        {
+            // task completion + wave-aggregated fetch: a wave-private chunk of kGChunk task ids per atomic on the queue word
+            const bool need_task = mode == M_NONE && s_gen == s_end && !queue_empty;
+            const unsigned long long need_mask = __ballot(need_task);
+            if (need_mask != 0ull) {
+                if (need_task && task_valid) K.cells[task] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+                const uint32_t cnt = (uint32_t)__popcll(need_mask);
+                const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
+                const uint32_t avail = chunk_end - chunk_next;
+                uint32_t base_old = chunk_next, base_new = 0;
+                if (cnt > avail) {
+                    const int leader = __ffsll((long long)need_mask) - 1;
+                    uint32_t nb = 0;
+                    if ((int)lane == leader) nb = atomicAdd(K.queue, (uint32_t)kGChunk);
+                    base_new = __builtin_amdgcn_readfirstlane(__shfl(nb, leader));
+                    chunk_next = base_new + (cnt - avail);
+                    chunk_end = base_new + (uint32_t)kGChunk;
+                } else {
+                    chunk_next += cnt;
+                }
+                const uint32_t base = rank < avail ? base_old : base_new - avail;
+                if (need_task) {
+                    task = base + rank;
+                    task_valid = task < K.ntasks;
+                    if (task_valid) {
+                        // task = ((pixel * 4 + cell) << nb_log2) | block: one block of a jitter cell's samples (D9)
+                        const uint32_t cellid = task >> K.nb_log2, blk = task & ((1u << K.nb_log2) - 1u);
+                        const uint32_t pix_local = cellid >> 2;
+                        cell = cellid & 3u;
+                        const uint32_t ry = pix_local / K.w;
+                        px = pix_local - ry * K.w;
+                        py = K.row_begin + (ry >> K.rb_log2) * K.rb_stride + (ry & K.rb_mask);
+                        const uint32_t pixel_idx = py * K.w + px;                      // GLOBAL index (smallpt.cpp:298)
+                        p0 = mix32(pixel_idx + K.s0); p1 = mix32(pixel_idx ^ K.s1);
+                        s_gen = blk * K.sb;
+                        s_end = s_gen + K.sb < K.samps ? s_gen + K.sb : K.samps;
+                        acc = mk(0, 0, 0);
+                    } else {
+                        queue_empty = true; s_gen = s_end = 0;
+                    }
+                }
+            }
+        }
+        if (mode == M_NONE && task_valid && s_gen < s_end) {
+            // camera ray of sample s_gen (smallpt.cpp:325-340 / :745-760), as in spt_kernel.hip phase C1
+            const uint32_t index_in_pixel = cell * K.samps + s_gen;                    // :306
+            k0 = mix32(p0 ^ (index_in_pixel * kGolden));
+            k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
+            const float u1 = rng_draw(k0 + ((1u << 28) | 0u) * kGolden, k1);
+            const float u2 = rng_draw(k0 + ((1u << 28) | 1u) * kGolden, k1);
+            const uint32_t sx = cell & 1u, sy = cell >> 1;
+            float ax, ay;
+            if (K.sampler == 0u) {
+                const float r1 = 2 * u1;                                               // tent filter :327-330
+                const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
+                const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
+                const float r2 = 2 * u2;
+                const float q2 = sqrt_rsq(r2 < 1 ? r2 : 2 - r2);
+                const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
+                // :331-332 in double like the reference; a / w as the exact Markstein sequence (tools/verify_exact_math.c)
+                const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
+                const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
+                const double qx0 = tx * K.inv_w, qy0 = ty * K.inv_h;
+                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)K.w, tx), K.inv_w, qx0);
+                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)K.h, ty), K.inv_h, qy0);
+                ax = (float)(qx - .5); ay = (float)(qy - .5);
+            } else {
+                const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;  // :750
+                const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);          // :753-758
+                const float nx = (((float)px + 0.5f) + fx) * K.inv_wf;                   // :628-631
+                const float ny = (((float)py + 0.5f) + fy) * K.inv_hf;
+                ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;                                // :633
+            }
+            const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
+            const float inv = rcp_exact(sqrt_exact(dot(dd, dd)));
+            p.o = cam_o + dd * K.cam_push;                                             // :333
+            p.d = dd * inv;                                                            // normalize(d)
+            p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; p.rbase = k0;                // :338-339
+            ++s_gen;
+            mode = M_FRESH;
+        }
+        if (__ballot(mode != M_NONE) == 0ull) break;             // no lane has a path, a pending child, a sample or a task left
+
+        // ================= B: new rays: ray test, always-tested spheres, start of the walk =================
+        {
+            const bool fresh = mode == M_FRESH;
+            if (__ballot(fresh) != 0ull) {
+                bool ok = false;
+                if (fresh) {
+                    ++nbounce;
+                    near_key = kGInfKey; near_i = 0xFFFFFFFFu;
+                    ok = grid_ray_ok(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z);
+                }
+                for (uint32_t k = 0; k < G.nalways; ++k) {       // ascending indices, strict '<' (smallpt.cpp:61)
+                    const uint32_t i = s_always[k];
+                    const float4 g = s_geom[i];
+                    if (fresh && ok) {
+                        const uint32_t key = sphere_key_g(g, p.o, p.d);
+                        if (key < near_key) { near_key = key; near_i = i; }
+                    }
+                }
+                const unsigned long long bad = __ballot(fresh && !ok);
+                if (bad != 0ull) {                               // spt_grid.h (4): the exhaustive loop of smallpt.cpp:54-70
+                    n_fallback += (unsigned long long)__popcll(bad);
+                    for (uint32_t i = 0; i < G.n; ++i) {
+                        const float4 g = s_geom[i];
+                        if (fresh && !ok) {
+                            const uint32_t key = sphere_key_g(g, p.o, p.d);
+                            if (key < near_key) { near_key = key; near_i = i; }
+                        }
+                    }
+                }
+                if (fresh) {
+                    if (ok) {
+                        grid_walk_begin(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, w);
+                        const uint32_t h = s_cells[w.ci];        // the start cell is clamped into the table: never a border cell
+                        cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
+                        mode = M_WALK;
+                    } else {
+                        mode = M_HIT;
+                    }
+                }
+            }
+        }
+
+        // ================= C: walk =================
+        {
+            unsigned long long walk_mask = __ballot(mode == M_WALK);
+            // lanes that could do something else right now: a hit to shade, or (NONE) a sample / pending child / task to start
+            const uint32_t nwait = (uint32_t)__popcll(__ballot(mode == M_HIT || (mode == M_NONE && (!queue_empty || (task_valid && s_gen < s_end)))));
+            uint32_t nhit = 0;
+            while (walk_mask != 0ull) {
+                const uint32_t nwalk = (uint32_t)__popcll(walk_mask);
+                if (nwalk * 16u < (nwait + nhit) * leave_q) break;   // leave_q = 0: every walk runs to its end
+                const bool wt = cur < end;                       // cur == end for lanes outside the walk
+                const unsigned long long test_mask = __ballot(wt);
+                const uint32_t nt = (uint32_t)__popcll(test_mask);
+                if (2u * nt >= nwalk) {
+                    // ---- TEST: the next sphere of the lane's cell ----
+                    ++n_test_iters; n_tests += nt;
+                    if (wt) {
+                        const uint32_t i = s_refs[cur];
+                        ++cur;
+                        const uint32_t key = sphere_key_g(s_geom[i], p.o, p.d);
+                        // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
+                        if ((key < near_key || (key == near_key && i < near_i)) && key < kGInfKey) { near_key = key; near_i = i; }
+                    }
+                } else {
+                    // ---- STEP: leave the cell (all its spheres are tested) ----
+                    ++n_step_iters; n_steps += nwalk - nt;
+                    if (mode == M_WALK && !wt) {
+                        const float m = grid_walk_exit(w);
+                        const float near_t = __uint_as_float(near_key + kGEpsBias);    // 1e20 while nothing is hit
+                        if (!(m < near_t)) {
+                            mode = M_HIT;                         // spt_grid.h (3): every cell up to the hit has been visited
+                        } else {
+                            grid_walk_step(w, m);
+                            const uint32_t h = s_cells[w.ci];
+                            if (h == kGridBorder) {
+                                mode = M_HIT;                     // left the table
+                            } else {
+                                cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
+                            }
+                        }
+                        if (mode == M_HIT) { cur = 0; end = 0; }
+                    }
+                    walk_mask = __ballot(mode == M_WALK);
+                    nhit = nwalk - (uint32_t)__popcll(walk_mask) + nhit;
+                }
+            }
+        }
+
+        // ================= D: shadePaths for the lanes whose closest hit is known (smallpt.cpp:168-263 under D2-D6, D18, D19) =================
+        if (mode == M_HIT) {
+            ++n_shade_lanes;
+            mode = M_NONE;
+            if (near_key != kGInfKey) {                                                // else :168 miss (D13)
+                const uint32_t inst = near_i;
+                const float t = __uint_as_float(near_key + kGEpsBias);
+                const float4 gh = s_geom[inst];
+                const float4 me = K.mat[3 * inst + 0], mc = K.mat[3 * inst + 1];
+                const int refl = __float_as_int(me.w) & 3;
+                const f3 hx = p.o + p.d * t;                                           // scene.cpp:137
+                const f3 n = normalize<false>(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));   // scene.cpp:124
+                const f3 nl = dot(n, p.d) < 0 ? n : neg(n);                            // :174 (D2)
+                f3 f = mk(mc.x, mc.y, mc.z);                                           // :175
+                acc = acc + p.w * mk(me.x, me.y, me.z);                                // :179 (D4)
+                bool cont = true;
+                if (p.depth > 5) {                                                     // :188 (D5)
+                    if (rng_draw(p.rbase, k1) < mc.w) { const float4 mf = K.mat[3 * inst + 2]; f = mk(mf.x, mf.y, mf.z); }
+                    else cont = false;
+                }
+                if (cont) {
+                    const f3 off = nl * 0.02f;                                         // :172 (D3)
+                    f3 no = hx + off, nd, nf = f;
+                    if (refl == 0) {                                                   // DIFF :208-215
+                        const uint32_t u1bits = rng_draw_bits(p.rbase + kGolden, k1);
+                        const float r2 = rng_draw(p.rbase + 2u * kGolden, k1);
+                        const float r2s = sqrt_rsq(r2);
+                        float sn, cs;
+                        sincos2pi_bits(u1bits, sn, cs);                                // D17
+                        const f3 ww = nl;
+                        const bool ay = __builtin_fabsf(ww.x) >= 0.1f;                // (double)fabs(w.x) > .1, :211
+                        const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
+                        const float s2 = ay ? ww.x : ww.y;
+                        const float qu = ww.z * ww.z + s2 * s2;                        // dot(ur, ur) with the zero term dropped
+                        const f3 uu = ur * rcp_exact<false>(sqrt_rsq<true, true>(qu));
+                        const f3 vv = cross(ww, uu);
+                        nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq<true, true>(1 - r2));   // :212
+                    } else {
+                        nd = p.d - n * 2.0f * dot(n, p.d);                             // :218 reflRay
+                        if (refl == 2) {                                               // REFR :225-263
+                            const bool into = dot(n, nl) > 0;
+                            const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;
+                            const float ddn = dot(p.d, nl);
+                            const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
+                            if (!(cos2t < 0)) {                                        // else TIR :232-236
+                                const f3 tdir = normalize<true>(p.d * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t))));   // :238
+                                const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);
+                                const float cc = 1 - (into ? -ddn : dot(tdir, n));
+                                const float c2 = cc * cc;
+                                const float Re = R0 + (1 - R0) * c2 * c2 * cc;
+                                const float Tr = 1 - Re;
+                                const f3 xin = hx - off;
+                                if (p.depth <= 2) {                                    // :248 split (D6)
+                                    const f3 tw = p.w * (f * Tr);
+                                    if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
+                                        float* e = gstack + sp * 12;
+                                        e[0] = xin.x; e[1] = xin.y; e[2] = xin.z; e[3] = tdir.x; e[4] = tdir.y; e[5] = tdir.z;
+                                        e[6] = tw.x; e[7] = tw.y; e[8] = tw.z;
+                                        e[9] = __uint_as_float((p.depth + 1u) | ((p.branch | (1u << p.depth)) << 16));
+                                        ++sp;
+                                    }
+                                    nf = f * Re;
+                                } else {
+                                    const float Pr = 0.25f + 0.5f * Re;
+                                    const bool pick_refl = rng_draw(p.rbase + kGolden, k1) < Pr;
+                                    const float inv = rcp_exact(pick_refl ? Pr : 1.f - Pr);
+                                    nf = f * (pick_refl ? Re : Tr) * inv;
+                                    if (!pick_refl) { no = xin; nd = tdir; }
+                                }
+                            }
+                        }
+                    }
+                    // extend() smallpt.cpp:120-123 + D18 + D19
+                    p.w = p.w * nf;
+                    p.o = no; p.d = nd;
+                    ++p.depth;
+                    p.rbase += 4u * kGolden;
+                    if (p.depth >= SPT_K_MAX_DEPTH) ++nkill;
+                    else if (!(p.w.x == 0.f && p.w.y == 0.f && p.w.z == 0.f)) mode = M_FRESH;
+                }
+            }
+        }
+    }
+
+    // stats: wave reduction then one atomic per wave
+    unsigned long long nb = nbounce, nk = nkill, ns = n_shade_lanes;
+    for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nk += __shfl_down(nk, off); ns += __shfl_down(ns, off); }
+    if (lane == 0) {
+        atomicAdd(&K.counters[0], nb);
+        if (nk) atomicAdd(&K.counters[1], nk);
+        atomicAdd(&K.counters[2], n_steps); atomicAdd(&K.counters[3], n_tests);
+        atomicAdd(&K.counters[4], n_step_iters); atomicAdd(&K.counters[5], n_test_iters);
+        atomicAdd(&K.counters[6], n_fallback); atomicAdd(&K.counters[7], n_rounds);
+        if (timed_out) atomicAdd(&K.counters[8], 1ull);
+        atomicAdd(&K.counters[9], ns);
+        atomicMax(&K.counters[12], __builtin_amdgcn_s_memtime() - t_start);
+    }
+}
+
+}  // namespace spt
+
+extern "C" size_t spt_grid_lds_bytes(const spt::GridParams* G)
+{
+    return (size_t)(G->n ? G->n : 1u) * 16u + (size_t)G->ncells * 4u + (size_t)G->nalways * 4u + (((size_t)G->nrefs + 1u) / 2u) * 4u;
+}
+extern "C" int spt_grid_block_threads(void) { return spt::kGridBlock; }
+extern "C" size_t spt_grid_stack_floats(uint32_t blocks) { return (size_t)blocks * spt::kGridBlock * 36u; }
+
+extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
+                                      const uint32_t* d_always, uint32_t blocks, uint32_t leave_q, hipStream_t stream)
+{
+    const size_t lds = spt_grid_lds_bytes(G);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::gridkernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spt::gridkernel, dim3(blocks), dim3(spt::kGridBlock), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+    return hipGetLastError();
+}

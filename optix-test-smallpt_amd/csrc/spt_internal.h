@@ -15,7 +15,9 @@ extern "C" {
 /* Tuning knobs (0 = default).  blocks_per_cu caps the persistent grid; variant bits 0..7 = number of
  * waiting lanes that triggers a wave's glass-shading pass (0 = default 8), bit 8 = instrumented kernel
  * build (see spt_diag), bit 9 = 512-thread workgroups for tables above 256 spheres, bit 10 = force the megakernel where the pool kernel
- * would run, bits 12:11 = pool slots per wave (0: 160, 3: 128; 1: 96 and 2: 192 in -DSPT_POOL_SIZES builds).  Results never depend on these. */
+ * would run (and the grid kernel), bits 12:11 = pool slots per wave (0: 160, 3: 128; 1: 96 and 2: 192 in -DSPT_POOL_SIZES builds), bits 23:16 = grid kernel:
+ * 1 + q, a wave leaves its walk phase when 16 x walking lanes < q x waiting lanes (0 = default q = 16), bits 31:24 = grid cells per sphere
+ * (read by spt_set_scene; 0 = default 8).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
 /* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
  * out24[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters (24 words are written). */
@@ -26,7 +28,9 @@ int  spt_diag(spt_ctx* ctx, unsigned long long* out24);
  * cannot hang the GPU box. */
 int  spt_set_watchdog(spt_ctx* ctx, double seconds);
 /* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip),
- * 2 = mesh kernel (spt_mesh.hip, triangles), 3 = mesh kernel over a sphere hierarchy (spt_set_sphere_accel).
+ * 2 = mesh kernel (spt_mesh.hip, triangles), 3 = mesh kernel over a sphere hierarchy (SPT_ACCEL_BVH), 4 = grid kernel (spt_grid.hip).
+ * After a grid launch spt_diag returns out24[0..1] = cell steps / sphere tests of the walks, [2..3] = wave iterations of either kind,
+ * [4] = rays that took the exhaustive loop, [5] = rounds, [7] = shaded hits.
  * After a pool launch spt_diag returns out24[0..2] = batches per class (GEN, DIFF, REFR), [3..5] = lanes per class. */
 int  spt_last_kernel(spt_ctx* ctx);
 
@@ -53,6 +57,11 @@ int  spt_selftest_range(spt_ctx* ctx, int op, uint32_t first, uint32_t count, ui
 int  spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, char* why, uint32_t why_len);
 /* The same for the sphere hierarchy of spt_set_sphere_accel; out4 = {nodes, leaves, depth, always-tested spheres}. */
 int  spt_selftest_sphere_bvh(const spt_sphere* spheres, uint32_t n, uint32_t* out4, char* why, uint32_t why_len);
+/* Host-only self-test of the SPT_ACCEL_GRID builder (csrc/spt_grid.cpp): builds the uniform grid over the table at
+ * `cells_per_sphere` (0 = the default resolution) and checks that every sphere is listed in every cell its error-bound cube
+ * meets, that references are ascending and in range and that the ray test admits every origin inside the box.
+ * out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, 0}; 0 = valid, 2 = not usable / invalid, 1 = builder error. */
+int  spt_selftest_sphere_grid(const spt_sphere* spheres, uint32_t n, uint32_t cells_per_sphere, uint32_t* out8, char* why, uint32_t why_len);
 
 #ifdef __cplusplus
 }

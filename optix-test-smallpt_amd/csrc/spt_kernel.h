@@ -38,7 +38,7 @@ struct KParams {
                                    // (pool kernel: waves x slots x 3; megakernel / mesh kernel: threads x 3)
     // pool kernel (spt_pool.hip) only
     uint2* slot_state;             // waves x pool slots x {task id, next sample}
-    unsigned long long watchdog_ticks;  // s_memtime ticks after which a wave gives up (0 = never)
+    unsigned long long watchdog_ticks;  // pool and grid kernels: s_memtime ticks after which a wave gives up (0 = never)
 };
 
 // Triangle-mesh scene (spt_mesh.hip): the reference's TriMesh instances flattened into device tables
@@ -61,6 +61,12 @@ struct MParams {
 
 }  // namespace spt
 
+namespace spt { struct GridParams; }
+extern "C" size_t spt_grid_lds_bytes(const spt::GridParams* G);
+extern "C" int spt_grid_block_threads(void);
+extern "C" size_t spt_grid_stack_floats(uint32_t blocks);
+extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
+                                      const uint32_t* d_always, uint32_t blocks, uint32_t leave_q, hipStream_t stream);
 extern "C" size_t spt_mesh_lds_bytes(int bvh);
 extern "C" size_t spt_mesh_stack_floats(uint32_t blocks);
 extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream);

@@ -13,7 +13,7 @@ from ._lib import SptCamera, SptMaterial, SptMesh, SptMultiStats, SptStats, load
 from .scene import HIT_DTYPE, RAY_DTYPE, SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
-ACCEL_EXHAUSTIVE, ACCEL_BVH = 0, 1
+ACCEL_EXHAUSTIVE, ACCEL_BVH, ACCEL_GRID = 0, 1, 2
 
 
 class SptError(RuntimeError):
@@ -107,8 +107,8 @@ class Renderer:
         self._check(self._lib.spt_set_meshes(self._h, ms, len(meshes), mats))
 
     def set_sphere_accel(self, accel):
-        """ACCEL_EXHAUSTIVE (default) or ACCEL_BVH for sphere tables above 24 spheres: a hierarchy that is exhaustive-equivalent by
-        construction (include/smallpt_mi355x.h)."""
+        """How sphere tables above 24 spheres find their closest hit: ACCEL_GRID (default: uniform grid in LDS), ACCEL_BVH (hierarchy) --
+        both exhaustive-equivalent by construction (include/smallpt_mi355x.h) -- or ACCEL_EXHAUSTIVE."""
         self._check(self._lib.spt_set_sphere_accel(self._h, int(accel)))
 
     def set_mesh_accel(self, accel):
@@ -163,9 +163,9 @@ class Renderer:
         self._check(self._lib.spt_set_watchdog(self._h, float(seconds)))
 
     def last_kernel(self):
-        """'pool' (spt_pool.hip, material-sorted), 'mega' (spt_kernel.hip), 'mesh' (spt_mesh.hip, triangles) or 'sbvh' (spt_mesh.hip over a
-        sphere hierarchy) for the last launch."""
-        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh"}[self._lib.spt_last_kernel(self._h)]
+        """'pool' (spt_pool.hip, material-sorted), 'mega' (spt_kernel.hip), 'mesh' (spt_mesh.hip, triangles), 'sbvh' (spt_mesh.hip over a
+        sphere hierarchy) or 'grid' (spt_grid.hip, uniform grid over a large sphere table) for the last launch."""
+        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh", 4: "grid"}[self._lib.spt_last_kernel(self._h)]
 
     def render_interleaved_device(self, out_tensor, w, h, block_rows, world, rank, samps_per_cell, seed=0,
                                   normalise=False, camera=None, stream=None):

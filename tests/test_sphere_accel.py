@@ -1,6 +1,10 @@
-"""spt_set_sphere_accel: sphere tables above the pool kernel's 24 through a hierarchy that is exhaustive-equivalent by construction
-(every box is inflated per ray by twice the rounding-error bound of intersectAnalytic).  CPU: structure of
-the host builder.  GPU: images and bounce counts bit-identical to the oracle's exhaustive loop (smallpt.cpp:54-70)."""
+"""spt_set_sphere_accel: sphere tables above the pool kernel's 24 through a structure that is exhaustive-equivalent by construction --
+the uniform grid of csrc/spt_grid.h (default) or the hierarchy whose boxes are inflated per ray by the rounding-error bound of
+intersectAnalytic.  CPU: structure of the host builders; the grid's traversal arithmetic against the
+exhaustive loop on 700 k rays under ASan/UBSan (tests/sanitize/grid_main.cpp).  GPU: images and bounce counts bit-identical to
+the oracle's exhaustive loop (smallpt.cpp:54-70)."""
+import os
+import subprocess
 import ctypes as C
 
 import numpy as np
@@ -11,6 +15,13 @@ def _selftest(pkg, spheres):
     lib = pkg.load_library()
     out, why = (C.c_uint32 * 4)(), C.create_string_buffer(256)
     rc = lib.spt_selftest_sphere_bvh(spheres.ctypes.data_as(C.c_void_p), len(spheres), C.byref(out), why, 256)
+    return rc, list(out), why.value.decode()
+
+
+def _selftest_grid(pkg, spheres, density=0):
+    lib = pkg.load_library()
+    out, why = (C.c_uint32 * 8)(), C.create_string_buffer(256)
+    rc = lib.spt_selftest_sphere_grid(spheres.ctypes.data_as(C.c_void_p), len(spheres), density, C.byref(out), why, 256)
     return rc, list(out), why.value.decode()
 
 
@@ -53,6 +64,75 @@ def test_sphere_hierarchy_structure(pkg):
     assert rc == 1 and "non-finite" in why
 
 
+def test_sphere_grid_structure(pkg):
+    cases = {"one": pkg.make_spheres([(1.0, (0, 0, 0), (0, 0, 0), (.5, .5, .5), 0)]), "config 5": pkg.random_spheres(1024, 1024),
+             "cluster 300": _cluster_scene(pkg, 300, 1), "no huge": _cluster_scene(pkg, 100, 2, huge=False), "4096": _cluster_scene(pkg, 4096, 3),
+             "identical": pkg.make_spheres([(1.0, (1, 2, 3), (0, 0, 0), (.5, .5, .5), 0)] * 50)}
+    for name, sc in cases.items():
+        for density in (0, 2, 40):
+            rc, (dx, dy, dz, refs, always, nbytes, usable, _), why = _selftest_grid(pkg, sc, density)
+            assert rc == 0 and usable == 1, (name, density, rc, why)
+            assert 1 <= dx <= 128 and 1 <= dy <= 128 and 1 <= dz <= 128 and always <= 32, (name, dx, dy, dz, always)
+            assert nbytes + 16 * max(1, len(sc)) <= 150 * 1024, (name, nbytes)          # tables + sphere records fit one CU's LDS
+            if name == "config 5":
+                assert always == 7                   # the six walls and the light are tested for every ray
+    bad = pkg.make_spheres([(1.0, (np.nan, 0, 0), (0, 0, 0), (.5, .5, .5), 0)] * 30)
+    rc, _, why = _selftest_grid(pkg, bad)
+    assert rc == 1 and "non-finite" in why
+
+
+def test_sphere_grid_walk_equals_exhaustive_on_cpu(tmp_path):
+    """The traversal arithmetic the kernel uses (csrc/spt_grid.h) + the builder against the exhaustive loop, on the CPU: random,
+    grazing, axis-parallel, on-cell-face, almost-zero-component, drifted-length and far-origin rays over six kinds of tables;
+    an under-registered grid must fail (negative control)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "grid_main"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "sanitize", "grid_main.cpp"),
+                           os.path.join(root, "optix-test-smallpt_amd", "csrc", "spt_grid.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "mismatches 0," in r.stdout and "grid harness ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle):
+    """Default mode: tables above 24 spheres run the grid kernel; image and bounce count equal the oracle's exhaustive loop."""
+    scenes = [("cluster 25", _cluster_scene(pkg, 25, 5)), ("cluster 100", _cluster_scene(pkg, 100, 6)), ("cluster 600", _cluster_scene(pkg, 600, 7)),
+              ("open 257", _cluster_scene(pkg, 257, 8, huge=False)), ("config 5", pkg.random_spheres(1024, 1024)), ("cluster 4096", _cluster_scene(pkg, 4096, 9)),
+              ("identical 50", pkg.make_spheres([(1.0, (50, 40, 80), (1, 1, 1), (.5, .5, .5), 0)] * 50))]
+    for name, sc in scenes:
+        w, h, samps, seed = (40, 30, 2, 3) if len(sc) < 600 else (32, 20, 1, 4)
+        renderer.set_scene(sc)
+        img, st = renderer.render(w, h, samps, seed=seed)
+        assert renderer.last_kernel() == "grid", name
+        ref, rst = oracle.render(sc, w, h, samps, seed=seed)
+        assert np.array_equal(img, ref), (name, int((img != ref).any(axis=-1).sum()))
+        assert st["bounces"] == rst["bounces"] and st["max_depth_kills"] == rst["max_depth_kills"], name
+        for cam in (pkg.pinhole_camera(org=(50, 45, 160), vz=(0, 0, -1)),               # the viewer's camera, inside the scene
+                    pkg.pinhole_camera(org=(50, 45, 2000), vz=(0, 0, -1))):             # far outside: rays beyond the grid's error bound take the exhaustive loop
+            img, st = renderer.render(w, h, samps, seed=seed + 1, camera=cam)
+            ref, rst = oracle.render(sc, w, h, samps, seed=seed + 1, camera=cam)
+            assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"], (name, "pinhole")
+    # several D9 sample blocks per cell, a ragged size and the normalised output
+    sc = pkg.random_spheres(1024, 1024)
+    renderer.set_scene(sc)
+    img, st = renderer.render(9, 7, 70, seed=11, normalise=True)
+    ref, rst = oracle.render(sc, 9, 7, 70, seed=11, normalise=True)
+    assert renderer.last_kernel() == "grid" and np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+    # the walk-phase policy (when a wave leaves its walk phase) and the resolution never change the image
+    for variant in (1 << 16, 5 << 16, 65 << 16, (1 << 16) | (3 << 24), 40 << 24):
+        renderer.set_tuning(0, variant)
+        renderer.set_scene(sc)
+        img2, st2 = renderer.render(32, 20, 1, seed=4)
+        ref2, rst2 = oracle.render(sc, 32, 20, 1, seed=4)
+        assert np.array_equal(img2, ref2) and st2["bounces"] == rst2["bounces"], hex(variant)
+    renderer.set_tuning(0, 0)
+    renderer.set_scene(pkg.cornell9())
+    renderer.render(8, 8, 1)
+    assert renderer.last_kernel() == "pool"
+
+
 @pytest.mark.gpu
 def test_sphere_hierarchy_images_equal_oracle(pkg, renderer, oracle):
     scenes = [("cluster 25", _cluster_scene(pkg, 25, 5)), ("cluster 100", _cluster_scene(pkg, 100, 6)), ("cluster 600", _cluster_scene(pkg, 600, 7)),
@@ -80,5 +160,5 @@ def test_sphere_hierarchy_images_equal_oracle(pkg, renderer, oracle):
         renderer.render(8, 8, 1)
         assert renderer.last_kernel() == "mega"
     finally:
-        renderer.set_sphere_accel(pkg.ACCEL_EXHAUSTIVE)
+        renderer.set_sphere_accel(pkg.ACCEL_GRID)            # the default
         renderer.set_scene(pkg.cornell9())

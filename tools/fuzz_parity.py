@@ -14,7 +14,7 @@ r.set_watchdog(60.0)
 kernels = {}
 t0 = time.time(); cases = 0; bad = 0; last_note = t0
 while time.time() - t0 < budget:
-    n = int(rs.choice([1, 2, 3, 5, 9, 17, 24, 25, 40, 100, 257, 600]))
+    n = int(rs.choice([1, 2, 3, 5, 9, 17, 24, 25, 40, 100, 257, 600, 1500]))
     rows = []
     for i in range(n):
         kind = rs.rand()
@@ -34,7 +34,7 @@ while time.time() - t0 < budget:
     seed = int(rs.randint(0, 2**31)) * int(rs.choice([1, 2**20]))
     cam = None if rs.rand() < 0.6 else pkg.pinhole_camera(org=(50, 45, 250), vz=(0, 0, -1))
     norm = bool(rs.rand() < 0.5)
-    r.set_sphere_accel(pkg.ACCEL_BVH if rs.rand() < 0.5 else pkg.ACCEL_EXHAUSTIVE)     # tables above 24 spheres: hierarchy or megakernel
+    r.set_sphere_accel([pkg.ACCEL_GRID, pkg.ACCEL_GRID, pkg.ACCEL_BVH, pkg.ACCEL_EXHAUSTIVE][rs.randint(4)])     # tables above 24 spheres: grid (default), hierarchy or megakernel
     r.set_scene(sc)
     img, st = r.render(w, h, samps, seed=seed, normalise=norm, camera=cam)
     ref, rst = orc.render(sc, w, h, samps, seed=seed, normalise=norm, camera=cam)
