@@ -302,7 +302,7 @@ static int build_sphere_grid_tables(spt_ctx* c)
     if ((size_t)c->n * 16u + 8192u > (size_t)150 * 1024) { c->grid_why = "sphere records alone exceed the LDS"; return 0; }
     spt::SphereGrid g;
     const uint32_t dsel = (c->variant >> 24) & 0xFFu;
-    spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 8.0, grid_table_budget(c->n), g);
+    spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, grid_table_budget(c->n), g);
     if (!g.usable) { c->grid_why = g.why; return 0; }
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
@@ -367,7 +367,7 @@ int spt_selftest_sphere_grid(const spt_sphere* s, uint32_t n, uint32_t cells_per
         std::vector<float> radius(n);
         for (uint32_t i = 0; i < n; ++i) { geom[i] = make_float4(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius); radius[i] = s[i].radius; }
         spt::SphereGrid g;
-        spt::build_sphere_grid(geom.data(), radius.data(), n, cells_per_sphere ? (double)cells_per_sphere : 8.0, grid_table_budget(n), g);
+        spt::build_sphere_grid(geom.data(), radius.data(), n, cells_per_sphere ? (double)cells_per_sphere : 4.0, grid_table_budget(n), g);
         std::string reason = g.why;
         const bool ok = g.usable && spt::validate_sphere_grid(geom.data(), radius.data(), n, g, reason);
         if (out8) {
@@ -758,8 +758,11 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
 
     // ---- large sphere table through its uniform grid (spt_grid.hip): the default above the pool kernel's limit ----
     if (!c->mesh_scene && c->sphere_accel == SPT_ACCEL_GRID && c->grid_ready && cam_big <= 1e15f && !(c->variant & 0x400u)) {
-        const uint32_t blocks = (uint32_t)c->cu_count * (c->blocks_per_cu ? c->blocks_per_cu : 1u);   // one 1024-thread workgroup per CU shares the LDS tables
-        const size_t need_stack = spt_grid_stack_floats(blocks);
+        // one 1024-thread workgroup per CU shares the LDS tables (tuning: variant bits 15:13 = threads / 128 - 1 ... 0 = 1024; blocks_per_cu)
+        const uint32_t tsel = (c->variant >> 13) & 7u;
+        const uint32_t threads = tsel ? 128u * (tsel + 1u) : (uint32_t)spt_grid_block_threads();
+        const uint32_t blocks = (uint32_t)c->cu_count * (c->blocks_per_cu ? c->blocks_per_cu : 1u);
+        const size_t need_stack = spt_grid_stack_floats(blocks, threads);
         if (need_stack > c->stack_cap) {
             if (c->d_stack) (void)hipFree(c->d_stack);
             c->d_stack = nullptr; c->stack_cap = 0;
@@ -771,7 +774,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         const uint32_t lsel = (c->variant >> 16) & 0xFFu;
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));
-        SPT_HIP(c, spt_grid_launch(&P, &c->grid, c->d_grid_cells, c->d_grid_refs, c->d_grid_always, blocks, lsel ? lsel - 1u : 16u, st));
+        SPT_HIP(c, spt_grid_launch(&P, &c->grid, c->d_grid_cells, c->d_grid_refs, c->d_grid_always, blocks, threads, lsel ? lsel - 1u : 16u, (c->variant & 0x100u) ? 1 : 0, st));
         SPT_HIP(c, hipEventRecord(c->ev_mid, st));
         SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
@@ -781,7 +784,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         c->last = spt_stats{};
         c->last.samples = npix * 4ull * samps;
         c->last.grid_blocks = blocks;
-        c->last.block_threads = (uint32_t)spt_grid_block_threads();
+        c->last.block_threads = threads;
         return 0;
     }
 

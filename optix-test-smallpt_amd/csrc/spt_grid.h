@@ -57,7 +57,7 @@ struct GridParams {
 struct GridWalk {
     float tx, ty, tz;                              // ray parameter at which the walk leaves the current cell along x / y / z
     float dtx, dty, dtz;                           // parameter per cell
-    int32_t sx, sy, sz;                            // linear-index step per axis (sign included)
+    int32_t sx, sy, sz;                            // linear-index step per axis, sign included (+-1, +-stride_y, +-stride_z)
     uint32_t ci;                                   // linear index of the current cell in the bordered table
 };
 
@@ -82,8 +82,8 @@ SPT_HD bool grid_ray_ok(const GridParams& G, float ox, float oy, float oz, float
 }
 
 // One axis of the start of a walk: cell index (clamped into the table), exit parameter, parameter per cell, index step.
-SPT_HD void grid_axis_begin(float o, float d, float gmin, float cell, float inv_cell, int32_t dim, int32_t stride,
-                            int32_t& idx, float& t, float& dt, int32_t& step)
+SPT_HD void grid_axis_begin(float o, float d, float gmin, float cell, float inv_cell, int32_t dim,
+                            int32_t& idx, float& t, float& dt, bool& neg)
 {
     const float f = (o - gmin) * inv_cell;
     const int32_t i = (int32_t)__builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)(dim - 1));   // clamped into the table (NaN -> 0)
@@ -93,16 +93,18 @@ SPT_HD void grid_axis_begin(float o, float d, float gmin, float cell, float inv_
     const bool moving = __builtin_fabsf(d) >= 0x1p-60f;           // else the ray never crosses a face of this axis (and iv may be inf)
     t = moving ? (b - o) * iv : __builtin_inff();
     dt = moving ? cell * __builtin_fabsf(iv) : 0.0f;
-    step = pos ? stride : -stride;
+    neg = !pos;
     idx = i;
 }
 
 SPT_HD void grid_walk_begin(const GridParams& G, float ox, float oy, float oz, float dx, float dy, float dz, GridWalk& w)
 {
     int32_t ix, iy, iz;
-    grid_axis_begin(ox, dx, G.gmin[0], G.cell[0], G.inv_cell[0], G.dim[0], 1, ix, w.tx, w.dtx, w.sx);
-    grid_axis_begin(oy, dy, G.gmin[1], G.cell[1], G.inv_cell[1], G.dim[1], G.stride_y, iy, w.ty, w.dty, w.sy);
-    grid_axis_begin(oz, dz, G.gmin[2], G.cell[2], G.inv_cell[2], G.dim[2], G.stride_z, iz, w.tz, w.dtz, w.sz);
+    bool nx, ny, nz;
+    grid_axis_begin(ox, dx, G.gmin[0], G.cell[0], G.inv_cell[0], G.dim[0], ix, w.tx, w.dtx, nx);
+    grid_axis_begin(oy, dy, G.gmin[1], G.cell[1], G.inv_cell[1], G.dim[1], iy, w.ty, w.dty, ny);
+    grid_axis_begin(oz, dz, G.gmin[2], G.cell[2], G.inv_cell[2], G.dim[2], iz, w.tz, w.dtz, nz);
+    w.sx = nx ? -1 : 1; w.sy = ny ? -G.stride_y : G.stride_y; w.sz = nz ? -G.stride_z : G.stride_z;
     w.ci = (uint32_t)((ix + 1) + G.stride_y * (iy + 1) + G.stride_z * (iz + 1));
 }
 
@@ -110,15 +112,19 @@ SPT_HD void grid_walk_begin(const GridParams& G, float ox, float oy, float oz, f
 SPT_HD float grid_walk_exit(const GridWalk& w) { return __builtin_fminf(w.tx, __builtin_fminf(w.ty, w.tz)); }
 
 // Steps into the next cell through the face reached at m = grid_walk_exit(w).
-SPT_HD void grid_walk_step(GridWalk& w, float m)
+// (The kernel keeps the fields of a GridWalk in separate registers: selecting between sx / sy / sz through the struct would make
+// the compiler index it in scratch memory.)
+SPT_HD void grid_walk_step(float& tx, float& ty, float& tz, float dtx, float dty, float dtz, int32_t sx, int32_t sy, int32_t sz, uint32_t& ci, float m)
 {
-    const bool isx = w.tx == m;
-    const bool isy = !isx & (w.ty == m);
+    const bool isx = tx == m;
+    const bool isy = !isx & (ty == m);
     const bool isz = !isx & !isy;
-    w.tx += isx ? w.dtx : 0.0f;
-    w.ty += isy ? w.dty : 0.0f;
-    w.tz += isz ? w.dtz : 0.0f;
-    w.ci += (uint32_t)(isx ? w.sx : (isy ? w.sy : w.sz));
+    tx += isx ? dtx : 0.0f;
+    ty += isy ? dty : 0.0f;
+    tz += isz ? dtz : 0.0f;
+    int32_t st = isy ? sy : sz;
+    st = isx ? sx : st;
+    ci += (uint32_t)st;
 }
 
 }  // namespace spt

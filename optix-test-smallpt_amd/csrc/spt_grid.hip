@@ -27,6 +27,13 @@ constexpr uint32_t kGEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) 
 constexpr uint32_t kGInfKey = 0x60AD78ECu - kGEpsBias;           // key of 1e20f (maths.h:16)
 constexpr int kGChunk = 64;                                      // task ids fetched from the global queue per atomic
 
+#ifndef SPT_GRID_MULTISTEP
+#define SPT_GRID_MULTISTEP 0                                     // STEP body: keep stepping through empty cells while half of the steppers still do
+#endif
+#ifndef SPT_GRID_PREFETCH
+#define SPT_GRID_PREFETCH 0                                      // fetch the index of the next sphere reference one test ahead
+#endif
+
 enum : uint32_t { M_NONE = 0, M_FRESH = 1, M_WALK = 2, M_HIT = 3 };
 
 __device__ __forceinline__ uint32_t lane_id_g() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -46,21 +53,22 @@ __device__ __forceinline__ uint32_t sphere_key_g(const float4 g, f3 o, f3 d)
 
 struct GPath { f3 o, d, w; uint32_t depth, branch, rbase; };
 
+// STATS: walk statistics and per-phase wave time (s_memtime) for tools/bench_grid.py; the product build carries none of it
+template <bool STATS>
 __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
                                                          const uint16_t* __restrict__ g_refs, const uint32_t* __restrict__ g_always, uint32_t leave_q)
 {
     extern __shared__ float4 s_geom[];                           // n sphere records, then the grid tables
     uint32_t* const s_cells = reinterpret_cast<uint32_t*>(s_geom + (G.n ? G.n : 1u));
-    uint32_t* const s_always = s_cells + G.ncells;
-    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_always + G.nalways);
-    for (uint32_t i = threadIdx.x; i < G.n; i += kGridBlock) s_geom[i] = K.geom[i];
-    for (uint32_t i = threadIdx.x; i < G.ncells; i += kGridBlock) s_cells[i] = g_cells[i];
-    for (uint32_t i = threadIdx.x; i < G.nalways; i += kGridBlock) s_always[i] = g_always[i];
-    for (uint32_t i = threadIdx.x; i < G.nrefs; i += kGridBlock) s_refs[i] = g_refs[i];
+    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_cells + G.ncells);   // nrefs cell references, then the always-tested list, one spare
+    for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) s_geom[i] = K.geom[i];
+    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) s_cells[i] = g_cells[i];
+    for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_refs[i] = g_refs[i];
+    for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
     __syncthreads();
 
     const uint32_t lane = lane_id_g();
-    const uint32_t gthread = blockIdx.x * kGridBlock + threadIdx.x;
+    const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
     float* const gstack = K.stack + (size_t)gthread * (3 * 12);  // 3 pending transmitted children x 12 words per thread
     const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
     const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
@@ -73,19 +81,27 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
     uint32_t task = 0, sp = 0, s_gen = 0, s_end = 0, px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
     GPath p{mk(0, 0, 0), mk(0, 0, 1), mk(0, 0, 0), 0u, 0u, 0u};
     f3 acc = mk(0, 0, 0);
-    GridWalk w{};
-    uint32_t cur = 0, end = 0;                                   // references of the current cell still to test; cur == end outside the walk
+    float wtx = 0.f, wty = 0.f, wtz = 0.f, wdx = 0.f, wdy = 0.f, wdz = 0.f;   // the lane's walk (GridWalk, spt_grid.h) in separate registers
+    int32_t wsx = 0, wsy = 0, wsz = 0;
+    uint32_t wci = 0;
+    uint32_t cur = 0, end = 0;                                   // references of the current cell still to test; end = 0 outside the walk
+    uint32_t nid = 0;                                            // sphere index of reference `cur` (fetched ahead)
     uint32_t near_key = kGInfKey, near_i = 0xFFFFFFFFu;
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;                      // wave-uniform: this wave's private range of task ids
     // statistics (wave-uniform counters, lane 0 reports)
-    unsigned long long n_steps = 0, n_tests = 0, n_step_iters = 0, n_test_iters = 0, n_fallback = 0, n_rounds = 0, n_shade_lanes = 0;
+    unsigned long long n_steps = 0, n_tests = 0, n_step_iters = 0, n_test_iters = 0, n_fallback = 0, n_shade_lanes = 0;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};                  // wave time in regeneration, walk begin, test bodies, step bodies, shading
+    unsigned long long ph_t = 0;
+#define GSTAMP(i) if (STATS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     bool timed_out = false;
+    uint32_t n_rounds = 0;
 
     for (;;) {
         ++n_rounds;
-        if ((n_rounds & 63ull) == 0ull && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
+        if ((n_rounds & 63u) == 0u && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
+        if (STATS) ph_t = __builtin_amdgcn_s_memtime();
         // ================= A: regeneration (smallpt.cpp:304-340, :252 pop) =================
         if (mode == M_NONE && sp > 0) {                          // pending transmitted child of the lane's current sample
             --sp;
@@ -178,6 +194,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             mode = M_FRESH;
         }
         if (__ballot(mode != M_NONE) == 0ull) break;             // no lane has a path, a pending child, a sample or a task left
+        GSTAMP(0)
 
         // ================= B: new rays: ray test, always-tested spheres, start of the walk =================
         {
@@ -186,11 +203,11 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 bool ok = false;
                 if (fresh) {
                     ++nbounce;
-                    near_key = kGInfKey; near_i = 0xFFFFFFFFu;
+                    near_key = kGInfKey; near_i = 0u;            // index 0 with the inf key: never replaced by another inf key, never taken for a hit
                     ok = grid_ray_ok(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z);
                 }
-                for (uint32_t k = 0; k < G.nalways; ++k) {       // ascending indices, strict '<' (smallpt.cpp:61)
-                    const uint32_t i = s_always[k];
+                for (uint32_t k = 0; k < G.nalways; ++k) {       // the walls and the light of a Cornell box: ascending indices, strict '<' (smallpt.cpp:61)
+                    const uint32_t i = s_refs[G.nrefs + k];
                     const float4 g = s_geom[i];
                     if (fresh && ok) {
                         const uint32_t key = sphere_key_g(g, p.o, p.d);
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 }
                 const unsigned long long bad = __ballot(fresh && !ok);
                 if (bad != 0ull) {                               // spt_grid.h (4): the exhaustive loop of smallpt.cpp:54-70
-                    n_fallback += (unsigned long long)__popcll(bad);
+                    if (STATS) n_fallback += (unsigned long long)__popcll(bad);
                     for (uint32_t i = 0; i < G.n; ++i) {
                         const float4 g = s_geom[i];
                         if (fresh && !ok) {
@@ -210,9 +227,12 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 }
                 if (fresh) {
                     if (ok) {
+                        GridWalk w;
                         grid_walk_begin(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, w);
-                        const uint32_t h = s_cells[w.ci];        // the start cell is clamped into the table: never a border cell
+                        wtx = w.tx; wty = w.ty; wtz = w.tz; wdx = w.dtx; wdy = w.dty; wdz = w.dtz; wsx = w.sx; wsy = w.sy; wsz = w.sz; wci = w.ci;
+                        const uint32_t h = s_cells[wci];         // the start cell is clamped into the table: never a border cell
                         cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
+                        if (SPT_GRID_PREFETCH && cur < end) nid = s_refs[cur];
                         mode = M_WALK;
                     } else {
                         mode = M_HIT;
@@ -221,56 +241,62 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             }
         }
 
+        GSTAMP(1)
         // ================= C: walk =================
         {
-            unsigned long long walk_mask = __ballot(mode == M_WALK);
-            // lanes that could do something else right now: a hit to shade, or (NONE) a sample / pending child / task to start
-            const uint32_t nwait = (uint32_t)__popcll(__ballot(mode == M_HIT || (mode == M_NONE && (!queue_empty || (task_valid && s_gen < s_end)))));
-            uint32_t nhit = 0;
-            while (walk_mask != 0ull) {
-                const uint32_t nwalk = (uint32_t)__popcll(walk_mask);
-                if (nwalk * 16u < (nwait + nhit) * leave_q) break;   // leave_q = 0: every walk runs to its end
+            uint32_t nwalk = (uint32_t)__popcll(__ballot(mode == M_WALK));
+            uint32_t nidle = (uint32_t)__popcll(__ballot(mode == M_HIT));   // lanes whose hit waits for shading
+            while (nwalk != 0u && nwalk * 16u >= nidle * leave_q) {      // leave_q = 0: every walk runs to its end
                 const bool wt = cur < end;                       // cur == end for lanes outside the walk
-                const unsigned long long test_mask = __ballot(wt);
-                const uint32_t nt = (uint32_t)__popcll(test_mask);
+                const uint32_t nt = (uint32_t)__popcll(__ballot(wt));
                 if (2u * nt >= nwalk) {
-                    // ---- TEST: the next sphere of the lane's cell ----
-                    ++n_test_iters; n_tests += nt;
+                    // ---- TEST: the next sphere of the lane's cell (its index was fetched when the previous one was tested) ----
+                    if (STATS) { ++n_test_iters; n_tests += nt; }
                     if (wt) {
-                        const uint32_t i = s_refs[cur];
+                        const uint32_t i = SPT_GRID_PREFETCH ? nid : (uint32_t)s_refs[cur];
                         ++cur;
+                        if (SPT_GRID_PREFETCH && cur < end) nid = s_refs[cur];
                         const uint32_t key = sphere_key_g(s_geom[i], p.o, p.d);
                         // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
-                        if ((key < near_key || (key == near_key && i < near_i)) && key < kGInfKey) { near_key = key; near_i = i; }
+                        const bool better = (key < near_key) | ((key == near_key) & (i < near_i));
+                        near_key = better ? key : near_key;
+                        near_i = better ? i : near_i;
                     }
+                    GSTAMP(2)
                 } else {
-                    // ---- STEP: leave the cell (all its spheres are tested) ----
-                    ++n_step_iters; n_steps += nwalk - nt;
-                    if (mode == M_WALK && !wt) {
-                        const float m = grid_walk_exit(w);
-                        const float near_t = __uint_as_float(near_key + kGEpsBias);    // 1e20 while nothing is hit
-                        if (!(m < near_t)) {
-                            mode = M_HIT;                         // spt_grid.h (3): every cell up to the hit has been visited
-                        } else {
-                            grid_walk_step(w, m);
-                            const uint32_t h = s_cells[w.ci];
-                            if (h == kGridBorder) {
-                                mode = M_HIT;                     // left the table
-                            } else {
+                    // ---- STEP: leave the cell (all its spheres are tested); lanes that land in an empty cell go on while at least half
+                    // of the lanes that started stepping still do ----
+                    const uint32_t n0 = nwalk - nt;
+                    unsigned long long step_mask;
+                    do {
+                        const bool ws = mode == M_WALK && cur >= end;
+                        if (STATS) { ++n_step_iters; n_steps += (unsigned long long)__popcll(__ballot(ws)); }
+                        if (ws) {
+                            const float m = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));   // grid_walk_exit
+                            const float near_t = __uint_as_float(near_key + kGEpsBias);    // 1e20 while nothing is hit
+                            bool stop = !(m < near_t);           // spt_grid.h (3): every cell up to the hit has been visited
+                            if (!stop) {
+                                grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, m);
+                                const uint32_t h = s_cells[wci];
+                                stop = h == kGridBorder;         // left the table
                                 cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
                             }
+                            if (stop) { mode = M_HIT; end = 0; }  // end = 0: "cur < end" is false outside the walk
+                            else if (SPT_GRID_PREFETCH && cur < end) nid = s_refs[cur];
                         }
-                        if (mode == M_HIT) { cur = 0; end = 0; }
-                    }
-                    walk_mask = __ballot(mode == M_WALK);
-                    nhit = nwalk - (uint32_t)__popcll(walk_mask) + nhit;
+                        step_mask = __ballot(mode == M_WALK && cur >= end);
+                    } while (SPT_GRID_MULTISTEP && 2u * (uint32_t)__popcll(step_mask) >= n0 && step_mask != 0ull);
+                    const uint32_t still = (uint32_t)__popcll(__ballot(mode == M_WALK));
+                    nidle += nwalk - still;
+                    nwalk = still;
+                    GSTAMP(3)
                 }
             }
         }
 
         // ================= D: shadePaths for the lanes whose closest hit is known (smallpt.cpp:168-263 under D2-D6, D18, D19) =================
         if (mode == M_HIT) {
-            ++n_shade_lanes;
+            if (STATS) ++n_shade_lanes;
             mode = M_NONE;
             if (near_key != kGInfKey) {                                                // else :168 miss (D13)
                 const uint32_t inst = near_i;
@@ -350,20 +376,25 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 }
             }
         }
+        GSTAMP(4)
     }
+#undef GSTAMP
 
     // stats: wave reduction then one atomic per wave
     unsigned long long nb = nbounce, nk = nkill, ns = n_shade_lanes;
-    for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nk += __shfl_down(nk, off); ns += __shfl_down(ns, off); }
+    for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nk += __shfl_down(nk, off); if (STATS) ns += __shfl_down(ns, off); }
     if (lane == 0) {
         atomicAdd(&K.counters[0], nb);
         if (nk) atomicAdd(&K.counters[1], nk);
-        atomicAdd(&K.counters[2], n_steps); atomicAdd(&K.counters[3], n_tests);
-        atomicAdd(&K.counters[4], n_step_iters); atomicAdd(&K.counters[5], n_test_iters);
-        atomicAdd(&K.counters[6], n_fallback); atomicAdd(&K.counters[7], n_rounds);
         if (timed_out) atomicAdd(&K.counters[8], 1ull);
-        atomicAdd(&K.counters[9], ns);
-        atomicMax(&K.counters[12], __builtin_amdgcn_s_memtime() - t_start);
+        if (STATS) {
+            atomicAdd(&K.counters[2], n_steps); atomicAdd(&K.counters[3], n_tests);
+            atomicAdd(&K.counters[4], n_step_iters); atomicAdd(&K.counters[5], n_test_iters);
+            atomicAdd(&K.counters[6], n_fallback); atomicAdd(&K.counters[7], (unsigned long long)n_rounds);
+            atomicAdd(&K.counters[9], ns);
+            for (int i = 0; i < 5; ++i) atomicAdd(&K.counters[10 + i], ph[i]);
+            atomicAdd(&K.counters[15], __builtin_amdgcn_s_memtime() - t_start);
+        }
     }
 }
 
@@ -371,17 +402,20 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
 
 extern "C" size_t spt_grid_lds_bytes(const spt::GridParams* G)
 {
-    return (size_t)(G->n ? G->n : 1u) * 16u + (size_t)G->ncells * 4u + (size_t)G->nalways * 4u + (((size_t)G->nrefs + 1u) / 2u) * 4u;
+    return (size_t)(G->n ? G->n : 1u) * 16u + (size_t)G->ncells * 4u + (((size_t)G->nrefs + G->nalways + 2u) / 2u) * 4u;
 }
 extern "C" int spt_grid_block_threads(void) { return spt::kGridBlock; }
-extern "C" size_t spt_grid_stack_floats(uint32_t blocks) { return (size_t)blocks * spt::kGridBlock * 36u; }
+extern "C" size_t spt_grid_stack_floats(uint32_t blocks, uint32_t threads) { return (size_t)blocks * threads * 36u; }
 
 extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
-                                      const uint32_t* d_always, uint32_t blocks, uint32_t leave_q, hipStream_t stream)
+                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, hipStream_t stream)
 {
+    if (threads == 0 || threads > (uint32_t)spt::kGridBlock || (threads & 63u)) return hipErrorInvalidValue;
     const size_t lds = spt_grid_lds_bytes(G);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::gridkernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fn = stats ? reinterpret_cast<const void*>(&spt::gridkernel<true>) : reinterpret_cast<const void*>(&spt::gridkernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(spt::gridkernel, dim3(blocks), dim3(spt::kGridBlock), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+    if (stats) hipLaunchKernelGGL(spt::gridkernel<true>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+    else hipLaunchKernelGGL(spt::gridkernel<false>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
     return hipGetLastError();
 }

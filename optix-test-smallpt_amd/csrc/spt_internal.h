@@ -17,7 +17,7 @@ extern "C" {
  * build (see spt_diag), bit 9 = 512-thread workgroups for tables above 256 spheres, bit 10 = force the megakernel where the pool kernel
  * would run (and the grid kernel), bits 12:11 = pool slots per wave (0: 160, 3: 128; 1: 96 and 2: 192 in -DSPT_POOL_SIZES builds), bits 23:16 = grid kernel:
  * 1 + q, a wave leaves its walk phase when 16 x walking lanes < q x waiting lanes (0 = default q = 16), bits 31:24 = grid cells per sphere
- * (read by spt_set_scene; 0 = default 8).  Results never depend on these. */
+ * (read by spt_set_scene; 0 = default 4).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
 /* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
  * out24[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters (24 words are written). */

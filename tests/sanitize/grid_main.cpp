@@ -72,7 +72,7 @@ Hit through_grid(const std::vector<float4>& geom, const spt::SphereGrid& g, cons
         const float m = spt::grid_walk_exit(w);
         const float near_t = h.key == kInfKey ? 1e20f : u2f(h.key + kEpsBias);
         if (!(m < near_t)) break;
-        spt::grid_walk_step(w, m);
+        spt::grid_walk_step(w.tx, w.ty, w.tz, w.dtx, w.dty, w.dtz, w.sx, w.sy, w.sz, w.ci, m);
         ++st.steps;
     }
     return h;

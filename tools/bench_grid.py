@@ -11,7 +11,7 @@ import optix_test_smallpt_amd as pkg
 import oracle_binding as orc
 
 samps = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-variants = [int(v, 16) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+variants = [(int(v.split(":")[0], 16), int(v.split(":")[1]) if ":" in v else 0) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [(0, 0)]   # variant[:blocks per CU]
 scenes = [("config 5: 1024 spheres", pkg.random_spheres(1024, 1024), [100, 500])]
 if "--big" in sys.argv:
     scenes.append(("4096 spheres", pkg.random_spheres(4096, 7), [300]))
@@ -21,8 +21,8 @@ rows = []
 w, h = 1024, 768
 for name, sc, check_rows in scenes:
     refs = {row: orc.render(sc, w, h, samps, seed=0, normalise=True, row_begin=row, row_count=1)[0] for row in check_rows} if "--nocheck" not in sys.argv else {}
-    for variant in variants:
-        r.set_tuning(0, variant)
+    for variant, per_cu in variants:
+        r.set_tuning(per_cu, variant | (0x100 if "--stats" in sys.argv else 0))
         r.set_scene(sc)
         img, st = r.render(w, h, samps, seed=0, normalise=True)
         best = st
@@ -34,13 +34,15 @@ for name, sc, check_rows in scenes:
         exact = all(bool(np.array_equal(img[row:row + 1], ref)) for row, ref in refs.items())
         d = r.diag()
         rays = st["bounces"]
-        out = {"scene": name, "variant": hex(variant), "kernel": r.last_kernel(), "image": f"{w}x{h}", "spp": 4 * samps,
+        out = {"scene": name, "variant": hex(variant), "blocks": st["grid_blocks"], "threads": st["block_threads"], "kernel": r.last_kernel(), "image": f"{w}x{h}", "spp": 4 * samps,
                "kernel_ms": round(st["kernel_ms"], 2), "msamples_s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
                "bounces_per_sample": round(st["bounces"] / st["samples"], 4), "oracle_rows": len(refs), "bit_exact": exact}
-        if r.last_kernel() == "grid" and rays:
+        if r.last_kernel() == "grid" and rays and "--stats" in sys.argv:
             out.update({"steps_per_ray": round(d[0] / rays, 2), "tests_per_ray": round(d[1] / rays, 2),
                         "step_lanes": round(d[0] / max(1, d[2]) / 64, 3), "test_lanes": round(d[1] / max(1, d[3]) / 64, 3),
                         "exhaustive_rays": d[4], "rounds": d[5], "shade_lanes": round(d[7] / max(1, d[5]) / 64, 3)})
+            tot = max(1, d[13])
+            out["phase_share"] = {k: round(d[8 + i] / tot, 3) for i, k in enumerate(("regen", "begin", "test", "step", "shade"))}
         print(json.dumps(out), flush=True)
         rows.append(out)
 r.set_tuning(0, 0)
