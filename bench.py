@@ -104,13 +104,121 @@ def interactive(pkg, r, dev, frames=600):
             "ms_per_frame": round(dt * 1e3, 4), "value": round(w * h * 4 * samps / dt / 1e6, 1), "unit": "Msamples/s"}
 
 
+KERNEL_NAMES = {"pool": "spt::poolkernel<144,3>", "mega": "spt::megakernel", "grid": "spt::gridkernel<false>", "mesh": "spt::meshkernel<0>",
+                "sbvh": "spt::meshkernel<2>"}
+
+
+def _timed_launches(r, render, reps=3):
+    """One warm launch + `reps` timed ones; kernel time from the HIP events the library records on the launch stream."""
+    render()
+    kms, st = [], None
+    for _ in range(reps):
+        st = render()
+        kms.append(st["kernel_ms"])
+    return sum(kms) / len(kms), st
+
+
+def extra_sphere_config(pkg, label, scene, samps, reps=3):
+    """A further BASELINE.json configuration beside the headline: same image, same camera, own roofline block.
+    Tables that run the grid kernel (spt_grid.hip) do not test every sphere, so their algorithmic flops use the sphere tests the
+    kernel actually executes per closest-hit query (counted by its instrumented build at 16 spp; the count does not depend on the
+    spp); the formula's rate -- what the exhaustive loop of smallpt.cpp:54-70 would have to sustain -- is given beside it."""
+    import torch
+    r = pkg.Renderer(torch.cuda.current_device())
+    r.set_watchdog(120.0)
+    r.set_scene(scene)
+    out_t = torch.empty((H_PER_GPU, W, 3), dtype=torch.float32, device="cuda")
+
+    def render(s=samps):
+        r.render_rows_device(out_t, W, H_PER_GPU, 0, H_PER_GPU, s, seed=0, normalise=True)
+        return r.sync()
+
+    k_ms, st = _timed_launches(r, render, reps)
+    kern = r.last_kernel()
+    n = len(scene)
+    bbar = st["bounces"] / st["samples"]
+    fl_formula = flops_per_sample(bbar, n)
+    res = {"workload": f"{label}, {W}x{H_PER_GPU}, {4 * samps} spp, seed 0, smallpt camera + 2x2 tent filter", "spheres": n,
+           "kernel": KERNEL_NAMES.get(kern, kern), "launches": reps, "kernel_ms": round(k_ms, 3),
+           "value": round(st["samples"] / k_ms / 1e3, 1), "unit": "Msamples/s", "bounces_per_sample": round(bbar, 4)}
+    if kern == "grid":
+        r.set_tuning(0, 0x100)                                   # instrumented build: walk statistics
+        st4 = render(4)
+        d = r.diag()
+        r.set_tuning(0, 0)
+        rays = max(1, st4["bounces"])
+        always = 0
+        for x in scene:                                          # spheres more than 16 x the median radius are tested for every ray
+            always += 1 if abs(float(x["radius"])) > 16.0 * sorted(abs(float(y["radius"])) for y in scene)[n // 2] else 0
+        tests = d[1] / rays + min(always, 32)
+        fl = 45.0 + bbar * (17.0 * tests + 100.0)
+        ach = st["samples"] * fl / (k_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                           "traffic": None, "flops_per_sample": round(fl, 1), "sphere_tests_per_query": round(tests, 2),
+                           "cell_steps_per_query": round(d[0] / rays, 2), "exhaustive_loop_rays": d[4],
+                           "exhaustive_equivalent_tflops": round(st["samples"] * fl_formula / (k_ms * 1e-3) / 1e12, 2),
+                           "note": "algorithmic flops = 45 + B (17 T + 100) with T = sphere tests executed per closest-hit query (uniform grid, "
+                                   "exhaustive-equivalent by construction); exhaustive_equivalent_tflops prices the same image by SURVEY.md 8(d)'s "
+                                   "formula with T = N -- the work the reference's loop would do -- and is not a fraction of any peak"}
+    else:
+        ach = st["samples"] * fl_formula / (k_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                           "traffic": None, "flops_per_sample": round(fl_formula, 1)}
+    r.close()
+    return res
+
+
+def extra_mesh_config(pkg, samps, reps=3):
+    """The scene the reference ships (smallpt.cpp:31-34: r = 10 diffuse sphere + r = 600 light, 4096 triangles each, scene.h:91) through
+    the exhaustive triangle loop (scene.cpp:95-116), 256x256 (cpuRender's size, :274-275)."""
+    import torch
+    r = pkg.Renderer(torch.cuda.current_device())
+    meshes = [pkg.make_sphere_trimesh((50, 40.8, 81.6), 10.0), pkg.make_sphere_trimesh((50, 681.6 - .27, 81.6), 600.0)]
+    mats = [((0, 0, 0), (.75, .25, .25), pkg.DIFF), ((1, 1, 1), (0, 0, 0), pkg.DIFF)]
+    r.set_meshes(meshes, mats)
+    w = h = 256
+    out_t = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+
+    def render():
+        r.render_rows_device(out_t, w, h, 0, h, samps, seed=0, normalise=True)
+        return r.sync()
+
+    k_ms, st = _timed_launches(r, render, reps)
+    ntri = sum(m.triangle_count for m in meshes)
+    tests = st["bounces"] * ntri
+    ach = tests * 52.0 / (k_ms * 1e-3) / 1e12                   # 52 flop per triIntersect as the reference writes it (scene.cpp:52-70)
+    res = {"workload": f"the reference's shipped scene (2 spheres x 4096 triangles), {w}x{h}, {4 * samps} spp, seed 0, exhaustive triangle loop",
+           "triangles": ntri, "kernel": KERNEL_NAMES[r.last_kernel()], "launches": reps, "kernel_ms": round(k_ms, 3),
+           "value": round(st["samples"] / k_ms / 1e3, 2), "unit": "Msamples/s", "bounces_per_sample": round(st["bounces"] / st["samples"], 4),
+           "roofline": {"bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                        "traffic": None, "ray_triangle_tests_per_s": round(tests / (k_ms * 1e-3) / 1e9, 1), "flops_per_test": 52}}
+    r.close()
+    return res
+
+
+EXTRAS = ("config3", "config5", "mesh_4spp", "mesh_256spp")
+
+
+def run_extra(pkg, name):
+    if name == "config3":
+        return extra_sphere_config(pkg, "config 3: Cornell-9 (9 spheres)", pkg.cornell9(), 4096)
+    if name == "config5":
+        return extra_sphere_config(pkg, "config 5: 1024 spheres (6 walls + light + 1017 random, SplitMix64 seed 1024)", pkg.random_spheres(1024, 1024), 256)
+    if name == "mesh_4spp":
+        return extra_mesh_config(pkg, 1)
+    if name == "mesh_256spp":
+        return extra_mesh_config(pkg, 64)
+    raise SystemExit(f"unknown extra {name}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the d2h_inclusive and interactive measurements (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the d2h_inclusive, interactive and extra-configuration measurements (profiling runs)")
+    ap.add_argument("--only-extra", choices=EXTRAS, help="run one of the extra configurations alone and print its JSON (profiling runs)")
     ap.add_argument("--samps", type=int, default=SAMPS, help=argparse.SUPPRESS)   # dev only; default = config
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help=argparse.SUPPRESS)   # dev only: kernel A/B (csrc/spt_internal.h)
     args = ap.parse_args()
@@ -134,6 +242,9 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if args.only_extra:
+        print(json.dumps({args.only_extra: run_extra(pkg, args.only_extra)}), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -239,7 +350,7 @@ def main():
                        "spheres": N_SPHERES, "width": W, "height": h, "spp": 4 * samps, "rows_per_gpu": count},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "spt::poolkernel" if r.last_kernel() == "pool" else "spt::megakernel", "kernel_ms": round(k_s * 1e3, 3),
+                         "kernel": KERNEL_NAMES.get(r.last_kernel(), r.last_kernel()), "kernel_ms": round(k_s * 1e3, 3),
                          "flops_per_sample": round(fl, 1), "bounces_per_sample": round(bbar, 4),
                          "decomposition": decomposition,
                          "note": "FP32 VALU-bound (no MFMA-shaped work, HBM traffic ~12 B/pixel/launch); algorithmic "
@@ -259,6 +370,9 @@ def main():
             # pinhole Camera + box-in-cell sampling, device-resident accumulation -- frames/s of the render-thread loop.
             out["d2h_inclusive"] = d2h_inclusive(r, samps, max(1, min(10, args.steps)))
             out["interactive"] = interactive(pkg, r, dev)
+            # (3) the other single-GPU configurations of BASELINE.json and the reference's shipped triangle scene: one warm + three
+            # timed launches each, kernel time from the library's HIP events, each with its own roofline block
+            out["extras"] = {name: run_extra(pkg, name) for name in EXTRAS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
         print(json.dumps(out), flush=True)
