@@ -70,11 +70,6 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
     const uint32_t lane = lane_id_g();
     const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
     float* const gstack = K.stack + (size_t)gthread * (3 * 12);  // 3 pending transmitted children x 12 words per thread
-    const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
-    const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
-    const f3 cam_cx = mk(K.cam_cx[0], K.cam_cx[1], K.cam_cx[2]);
-    const f3 cam_cy = mk(K.cam_cy[0], K.cam_cy[1], K.cam_cy[2]);
-
     // per-lane state
     uint32_t mode = M_NONE;
     bool task_valid = false, queue_empty = false;
@@ -156,7 +151,16 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             }
         }
         if (mode == M_NONE && task_valid && s_gen < s_end) {
-            // camera ray of sample s_gen (smallpt.cpp:325-340 / :745-760), as in spt_kernel.hip phase C1
+            // camera ray of sample s_gen (smallpt.cpp:325-340 / :745-760), as in spt_kernel.hip phase C1.  The camera constants are
+            // read from the kernel-argument segment HERE (the empty asm keeps the compiler from hoisting ~30 scalar loads out of the
+            // main loop, where they would push the walk's scalars into spill lanes).
+            typedef const __attribute__((address_space(4))) KParams* KArgs;        // K is the first kernel argument
+            KArgs kc = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kc));
+            const f3 cam_o = mk(kc->cam_o[0], kc->cam_o[1], kc->cam_o[2]);
+            const f3 cam_d = mk(kc->cam_d[0], kc->cam_d[1], kc->cam_d[2]);
+            const f3 cam_cx = mk(kc->cam_cx[0], kc->cam_cx[1], kc->cam_cx[2]);
+            const f3 cam_cy = mk(kc->cam_cy[0], kc->cam_cy[1], kc->cam_cy[2]);
             const uint32_t index_in_pixel = cell * K.samps + s_gen;                    // :306
             k0 = mix32(p0 ^ (index_in_pixel * kGolden));
             k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             const float u2 = rng_draw(k0 + ((1u << 28) | 1u) * kGolden, k1);
             const uint32_t sx = cell & 1u, sy = cell >> 1;
             float ax, ay;
-            if (K.sampler == 0u) {
+            if (kc->sampler == 0u) {
                 const float r1 = 2 * u1;                                               // tent filter :327-330
                 const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
                 const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
@@ -174,20 +178,20 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 // :331-332 in double like the reference; a / w as the exact Markstein sequence (tools/verify_exact_math.c)
                 const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
                 const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
-                const double qx0 = tx * K.inv_w, qy0 = ty * K.inv_h;
-                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)K.w, tx), K.inv_w, qx0);
-                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)K.h, ty), K.inv_h, qy0);
+                const double qx0 = tx * kc->inv_w, qy0 = ty * kc->inv_h;
+                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)kc->w, tx), kc->inv_w, qx0);
+                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)kc->h, ty), kc->inv_h, qy0);
                 ax = (float)(qx - .5); ay = (float)(qy - .5);
             } else {
                 const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;  // :750
                 const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);          // :753-758
-                const float nx = (((float)px + 0.5f) + fx) * K.inv_wf;                   // :628-631
-                const float ny = (((float)py + 0.5f) + fy) * K.inv_hf;
+                const float nx = (((float)px + 0.5f) + fx) * kc->inv_wf;                   // :628-631
+                const float ny = (((float)py + 0.5f) + fy) * kc->inv_hf;
                 ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;                                // :633
             }
             const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
             const float inv = rcp_exact(sqrt_exact(dot(dd, dd)));
-            p.o = cam_o + dd * K.cam_push;                                             // :333
+            p.o = cam_o + dd * kc->cam_push;                                           // :333
             p.d = dd * inv;                                                            // normalize(d)
             p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; p.rbase = k0;                // :338-339
             ++s_gen;

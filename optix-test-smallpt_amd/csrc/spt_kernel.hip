@@ -664,10 +664,9 @@ extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int m
         if (mat_lds) return launch_variant<true, false, true, false, B0>(P, blocks, lds, stream);
         return b512 ? launch_variant<false, false, true, true, 512>(P, blocks, lds, stream) : launch_variant<false, false, true, true, 256>(P, blocks, lds, stream);
     }
-    if (mat_lds) {
-        if (bign) return guard ? launch_variant<true, true, false, true, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, true, B0>(P, blocks, lds, stream);
-        return guard ? launch_variant<true, true, false, false, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, false, B0>(P, blocks, lds, stream);
-    }
+    (void)bign;   // product launches always take the grouped closest-hit loop: the unrolled small-table form (n <= 24) spilled 26 scalar
+                  // registers and only served scenes the pool kernel refuses (range-guarded square root, colours outside [0,1])
+    if (mat_lds) return guard ? launch_variant<true, true, false, true, B0>(P, blocks, lds, stream) : launch_variant<true, false, false, true, B0>(P, blocks, lds, stream);
     if (b512) return guard ? launch_variant<false, true, false, true, 512>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 512>(P, blocks, lds, stream);
     return guard ? launch_variant<false, true, false, true, 256>(P, blocks, lds, stream) : launch_variant<false, false, false, true, 256>(P, blocks, lds, stream);
 }

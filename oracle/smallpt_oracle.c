@@ -581,6 +581,8 @@ static int render_scene(const orc_sphere* spheres, uint32_t n, const orc_mesh* m
     const uint32_t spp = 4 * samps;                                   /* :286 */
     uint32_t nb, sb;
     orc_sample_blocks(samps, &nb, &sb);
+    if (flags & (ORC_FLAG_SEQUENTIAL_CELLS | ORC_FLAG_SEQUENTIAL_PIXEL)) { nb = 1; sb = samps; }
+    const int one_sum = (flags & ORC_FLAG_SEQUENTIAL_PIXEL) != 0;
     /* The reference parallelises over rows (:317); here the unit is a chunk of 16 consecutive pixels so that a
      * band of a few rows still uses every core.  Pixels are independent, so the image does not depend on it. */
     const int64_t npix = (int64_t)row_count * w;
@@ -598,6 +600,7 @@ static int render_scene(const orc_sphere* spheres, uint32_t n, const orc_mesh* m
         {
             const uint32_t pixel_idx = py * w + px;                   /* :298 */
             f3 cell[4];
+            f3 pixsum = mk(0, 0, 0);                                  /* ORC_FLAG_SEQUENTIAL_PIXEL: the pixel's only accumulator */
             for (uint32_t sy = 0; sy < 2; ++sy)                       /* :299 */
                 for (uint32_t sx = 0; sx < 2; ++sx) {                 /* :301 */
                     const uint32_t g = sy * 2 + sx;                   /* :303 */
@@ -614,13 +617,13 @@ static int render_scene(const orc_sphere* spheres, uint32_t n, const orc_mesh* m
                             path_t p;
                             camera_ray(cam, w, h, px, py, sx, sy, u1, u2, &p.o, &p.d);
                             p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; /* :338-339 */
-                            trace_sample(&tc, p, k0, k1, &acc);
+                            trace_sample(&tc, p, k0, k1, one_sum ? &pixsum : &acc);
                         }
                         cellsum = blk == 0 ? acc : add(cellsum, acc);
                     }
                     cell[g] = cellsum;
                 }
-            f3 c = add(add(add(cell[0], cell[1]), cell[2]), cell[3]);
+            f3 c = one_sum ? pixsum : add(add(add(cell[0], cell[1]), cell[2]), cell[3]);
             if (flags & ORC_FLAG_NORMALISE) c = scl(c, 1.0f / (float)spp); /* :360, operator/= */
             st(out + ((size_t)r * w + px) * 3, c);
         }

@@ -75,6 +75,10 @@ enum { ORC_DIFF = 0, ORC_SPEC = 1, ORC_REFR = 2 };
 
 #define ORC_FLAG_NORMALISE        1u  /* divide by spp like cpuRender :358-361 (else raw sum like render() :813) */
 #define ORC_FLAG_NO_ZERO_WEIGHT_CUT 2u /* keep bouncing zero-weight paths (test of result-preservation) */
+#define ORC_FLAG_SEQUENTIAL_CELLS 4u   /* D9 with NB = 1 whatever the sample count: one accumulator per jitter cell (round 1's spec = smallpt's
+                                          per-subpixel accumulator); bounds what the block split of D9 changes (tests/test_oracle.py) */
+#define ORC_FLAG_SEQUENTIAL_PIXEL 8u   /* one accumulator per PIXEL, every emission event added in (cell, sample, DFS) order: the closest a
+                                          path-owning worker comes to `outColor[pixelIdx] +=` of smallpt.cpp:179, 358-361 */
 #define ORC_MAX_DEPTH 4096u            /* D18 */
 
 /* --- unit-level entry points (for known-answer tests) --- */

@@ -24,6 +24,10 @@ CASES = {
     "cornell9_e12_40x30_s1_seed0_sum": (lambda: pkg.cornell9(12.0), 40, 30, 1, 0, False),
     "rand64_33x17_s3_seed9": (lambda: pkg.random_spheres(64, 3), 33, 17, 3, 9, True),
     "rand1024_24x18_s1_seed2": (lambda: pkg.random_spheres(1024, 1024), 24, 18, 1, 2, True),
+    # D9 with several sample blocks per jitter cell (NB = 8 from 128 samples per cell, NB = 2 from 32): pins the block layout,
+    # so that a later change of the kernels' scheduling cannot move the summation spec silently
+    "cornell9_16x12_s128_seed5": (lambda: pkg.cornell9(), 16, 12, 128, 5, True),
+    "rand1024_12x8_s40_seed3": (lambda: pkg.random_spheres(1024, 1024), 12, 8, 40, 3, False),
 }
 
 

@@ -34,6 +34,8 @@ HIT_DTYPE = np.dtype([("dist", "<f4"), ("instId", "<u4"), ("triId", "<u4"), ("x"
 
 FLAG_NORMALISE = 1
 FLAG_NO_ZERO_WEIGHT_CUT = 2
+FLAG_SEQUENTIAL_CELLS = 4
+FLAG_SEQUENTIAL_PIXEL = 8
 _lib = None
 
 
@@ -91,7 +93,7 @@ def camera_from(other):
 
 
 def render(spheres, w, h, samps, seed=0, normalise=False, row_begin=0, row_count=None, threads=0,
-           camera=None, zero_cut=True):
+           camera=None, zero_cut=True, summation=None):
     """Oracle render of rows [row_begin, row_begin+row_count); returns ((rows, w, 3) float32, stats dict)."""
     spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
     if row_count is None:
@@ -102,6 +104,7 @@ def render(spheres, w, h, samps, seed=0, normalise=False, row_begin=0, row_count
     out = np.zeros((row_count, w, 3), dtype=np.float32)
     st = OrcStats()
     flags = (FLAG_NORMALISE if normalise else 0) | (0 if zero_cut else FLAG_NO_ZERO_WEIGHT_CUT)
+    flags |= {None: 0, "cells": FLAG_SEQUENTIAL_CELLS, "pixel": FLAG_SEQUENTIAL_PIXEL}[summation]   # D9 alternatives (bounding tests only)
     rc = lib().orc_render(spheres.ctypes.data_as(C.c_void_p), len(spheres), C.byref(cam), w, h, row_begin,
                           row_count, samps, seed, flags, threads, out.ctypes.data_as(C.c_void_p), C.byref(st))
     if rc:

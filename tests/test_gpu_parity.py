@@ -77,7 +77,7 @@ def test_parity_matrix(pkg, renderer, oracle, scene, w, h, samps, seed, norm):
 
 
 @pytest.mark.parametrize("name", ["cornell9_32x24_s2_seed1", "cornell9_e12_40x30_s1_seed0_sum",
-                                  "rand64_33x17_s3_seed9", "rand1024_24x18_s1_seed2"])
+                                  "rand64_33x17_s3_seed9", "rand1024_24x18_s1_seed2", "cornell9_16x12_s128_seed5", "rand1024_12x8_s40_seed3"])
 def test_golden_fixtures(pkg, renderer, name):
     """Committed fixtures (tests/golden/make_golden.py): no oracle needed at run time."""
     import golden.make_golden as mg
