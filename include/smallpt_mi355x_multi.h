@@ -19,6 +19,10 @@
  *     (unless SPT_MULTI_SELF_EXCHANGE is passed, which routes the root's band through a grouped self send/recv:
  *     a rehearsal of the RCCL path for boxes with a single GPU).
  *
+ * Failure: every device finishes (or fails) its rows before any device enqueues its part of the exchange, so a render error on
+ * one device (HIP error, kernel watchdog) makes spt_multi_render return non-zero with that device's message -- no peer is left
+ * waiting in ncclRecv -- and the object stays usable.
+ *
  * All functions return 0 on success; errors via spt_multi_last_error.  Not thread-safe; one call at a time.
  */
 #ifndef SMALLPT_MI355X_MULTI_H
@@ -56,6 +60,11 @@ int  spt_multi_device_count(const spt_multi* m);
 
 /* Uploads the sphere table to every device (spt_set_scene). */
 int  spt_multi_set_scene(spt_multi* m, const spt_sphere* spheres, uint32_t n);
+/* The triangle seam on every device: Intersector::addTriangleMesh + build (smallpt.cpp:437-447, spt_set_meshes) -- the scene the
+ * reference's live path renders (smallpt.cpp:818-842, 922) -- and the closest-hit modes (spt_set_mesh_accel, spt_set_sphere_accel). */
+int  spt_multi_set_meshes(spt_multi* m, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
+int  spt_multi_set_mesh_accel(spt_multi* m, int accel);
+int  spt_multi_set_sphere_accel(spt_multi* m, int accel);
 
 /* Row band of rank `rank` of `world` for an image of height h: rows split as evenly as possible, the first h % world
  * ranks get one more row; bands are in rank order = row order. */

@@ -96,11 +96,16 @@ MULTI_SYMBOLS = {
     "spt_multi_last_error": (C.c_char_p, [_P]),
     "spt_multi_device_count": (C.c_int, [_P]),
     "spt_multi_set_scene": (C.c_int, [_P, _P, C.c_uint32]),
+    "spt_multi_set_meshes": (C.c_int, [_P, C.POINTER(SptMesh), C.c_uint32, C.POINTER(SptMaterial)]),
+    "spt_multi_set_mesh_accel": (C.c_int, [_P, C.c_int]),
+    "spt_multi_set_sphere_accel": (C.c_int, [_P, C.c_int]),
     "spt_multi_row_band": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "spt_multi_render": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                    C.c_uint32, _P, C.POINTER(SptMultiStats)]),
     "spt_multi_framebuffer": (_P, [_P]),
 }
+
+MULTI_INTERNAL_SYMBOLS = {"spt_multi_set_rank_watchdog": (C.c_int, [_P, C.c_uint32, C.c_double])}   # csrc/spt_internal.h
 
 _lib = None
 _multi_lib = None
@@ -115,7 +120,7 @@ def load_multi_library():
     if not os.path.exists(MULTI_LIB_PATH):
         raise RuntimeError(f"{MULTI_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = C.CDLL(MULTI_LIB_PATH)
-    for name, (res, args) in MULTI_SYMBOLS.items():
+    for name, (res, args) in {**MULTI_SYMBOLS, **MULTI_INTERNAL_SYMBOLS}.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

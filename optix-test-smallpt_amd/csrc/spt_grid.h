@@ -129,7 +129,7 @@ SPT_HD void grid_walk_step(float& tx, float& ty, float& tz, float dtx, float dty
 
 }  // namespace spt
 
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if !defined(SPT_GRID_DEVICE_ONLY)      // host builder (spt_grid.hip, the kernel's translation unit, leaves it out)
 #include <string>
 #include <vector>
 

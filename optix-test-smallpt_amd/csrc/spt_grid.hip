@@ -17,6 +17,7 @@
 //     1: spt_grid.h (1)) run the exhaustive loop in place; spheres more than 16 x the median radius (the walls and the light of a
 //     Cornell box) are tested for every ray before the walk, which also bounds it.
 #include "spt_device.h"
+#define SPT_GRID_DEVICE_ONLY
 #include "spt_grid.h"
 #include "spt_kernel.h"
 

@@ -63,6 +63,11 @@ int  spt_selftest_sphere_bvh(const spt_sphere* spheres, uint32_t n, uint32_t* ou
  * out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, 0}; 0 = valid, 2 = not usable / invalid, 1 = builder error. */
 int  spt_selftest_sphere_grid(const spt_sphere* spheres, uint32_t n, uint32_t cells_per_sphere, uint32_t* out8, char* why, uint32_t why_len);
 
+/* libsmallpt_mi355x_multi.so: kernel watchdog (spt_set_watchdog) of ONE rank's context, so that a test can make exactly one
+ * device's render fail and check that spt_multi_render returns its error instead of hanging in the exchange. */
+struct spt_multi;
+int  spt_multi_set_rank_watchdog(struct spt_multi* m, uint32_t rank, double seconds);
+
 #ifdef __cplusplus
 }
 #endif

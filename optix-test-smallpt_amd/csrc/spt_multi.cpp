@@ -1,6 +1,7 @@
 // spt_multi.cpp -- include/smallpt_mi355x_multi.h: one host thread + context + stream per device, row bands, and
 // one RCCL exchange step (ncclSend per band, grouped ncclRecv into the root's framebuffer slices).
 #include "../../include/smallpt_mi355x_multi.h"
+#include "spt_internal.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -234,6 +235,53 @@ int spt_multi_set_scene(spt_multi* m, const spt_sphere* spheres, uint32_t n)
     }
 }
 
+// The triangle seam and the closest-hit modes on every device (spt_set_meshes / spt_set_mesh_accel / spt_set_sphere_accel)
+int spt_multi_set_meshes(spt_multi* m, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials)
+{
+    if (!m) return 1;
+    try {
+    return m->on_all([m, meshes, nmesh, materials](int i) {
+        Rank& r = m->ranks[(size_t)i];
+        if (spt_set_meshes(r.ctx, meshes, nmesh, materials)) r.error = spt_last_error(r.ctx);
+    });
+    } catch (const std::exception& e) {
+        return m->fail("spt_multi_set_meshes: %s", e.what());
+    }
+}
+
+int spt_multi_set_mesh_accel(spt_multi* m, int accel)
+{
+    if (!m) return 1;
+    try {
+    return m->on_all([m, accel](int i) {
+        Rank& r = m->ranks[(size_t)i];
+        if (spt_set_mesh_accel(r.ctx, accel)) r.error = spt_last_error(r.ctx);
+    });
+    } catch (const std::exception& e) {
+        return m->fail("spt_multi_set_mesh_accel: %s", e.what());
+    }
+}
+
+int spt_multi_set_sphere_accel(spt_multi* m, int accel)
+{
+    if (!m) return 1;
+    try {
+    return m->on_all([m, accel](int i) {
+        Rank& r = m->ranks[(size_t)i];
+        if (spt_set_sphere_accel(r.ctx, accel)) r.error = spt_last_error(r.ctx);
+    });
+    } catch (const std::exception& e) {
+        return m->fail("spt_multi_set_sphere_accel: %s", e.what());
+    }
+}
+
+// Test hook (csrc/spt_internal.h): kernel watchdog of ONE rank's context -- lets a test make exactly one rank's render fail
+int spt_multi_set_rank_watchdog(spt_multi* m, uint32_t rank, double seconds)
+{
+    if (!m || rank >= m->ranks.size()) return 1;
+    return spt_set_watchdog(m->ranks[rank].ctx, seconds);
+}
+
 void* spt_multi_framebuffer(spt_multi* m) { return m ? m->d_frame : nullptr; }
 
 int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h, uint32_t samps, uint64_t seed,
@@ -263,7 +311,9 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
     std::vector<size_t> stage_off(world + 1, 0);
     for (uint32_t p = 0; p < world; ++p) stage_off[p + 1] = stage_off[p] + (interleaved && p != 0 ? (size_t)rows_of(p, nullptr) * w * 3 : 0);
 
-    // 1. buffers + band render, every device on its own thread (ranks without rows -- more devices than rows -- skip)
+    // 1. buffers + band render, every device on its own thread (ranks without rows -- more devices than rows -- skip).  Every rank
+    // finishes its rows (stream synchronised, spt_sync) BEFORE any rank enqueues its part of the exchange: a rank whose render
+    // fails would otherwise leave its peers waiting in ncclRecv / ncclSend for ever.
     int rc = m->on_all([=, &stage_off](int i) {
         Rank& r = m->ranks[(size_t)i];
         uint32_t begin = 0;
@@ -295,15 +345,25 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
             dst = r.d_band;
         }
         r.stats = spt_stats{};
+        r.gather_ms = 0.f;
         if (count) {
             const int e = interleaved
                 ? spt_render_interleaved_device(r.ctx, cam, w, h, kBlockRows, world, (uint32_t)i, samps, seed, flags, dst, r.stream)
                 : spt_render_rows_device(r.ctx, cam, w, h, begin, count, samps, seed, flags, dst, r.stream);
             if (e) { r.error = spt_last_error(r.ctx); return; }
         }
-        // 2. the exchange step, enqueued behind the render on the same stream
-        r.gather_ms = 0.f;
-        if (m->use_rccl) {
+        RK_HIP(r, hipStreamSynchronize(r.stream));
+        if (count && spt_sync(r.ctx, &r.stats)) { r.error = spt_last_error(r.ctx); return; }
+    });
+    if (rc) return rc;                                         // nothing of the exchange has been enqueued: no peer is left waiting
+
+    // 2. the exchange step (RCCL): every rank's rows are complete
+    if (m->use_rccl) {
+        rc = m->on_all([=, &stage_off](int i) {
+            Rank& r = m->ranks[(size_t)i];
+            const uint32_t count = rows_of((uint32_t)i, nullptr);
+            const size_t band_fl = (size_t)count * w * 3;
+            RK_HIP(r, hipSetDevice(r.device));
             RK_HIP(r, hipEventRecord(r.ev_a, r.stream));
             if (i == 0) {
                 RK_NCCL(r, ncclGroupStart());
@@ -335,12 +395,11 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
                 RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
             }
             RK_HIP(r, hipEventRecord(r.ev_b, r.stream));
-        }
-        RK_HIP(r, hipStreamSynchronize(r.stream));
-        if (count && spt_sync(r.ctx, &r.stats)) { r.error = spt_last_error(r.ctx); return; }
-        if (m->use_rccl) RK_HIP(r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
-    });
-    if (rc) return rc;
+            RK_HIP(r, hipStreamSynchronize(r.stream));
+            RK_HIP(r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
+        });
+        if (rc) return rc;
+    }
 
     // 2'. copy transport (SPT_MULTI_COPY_EXCHANGE): every rank has finished its rows (stream synchronised above); the root
     // pulls the packed rows with peer copies and scatters / places them exactly like the RCCL path does.

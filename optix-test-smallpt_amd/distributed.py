@@ -67,7 +67,22 @@ class FrameAssembler:
             self.frame = None
             self.band = torch.empty((self.count, w, 3), dtype=dtype, device=device)
 
-    def gather(self):
+    def all_ok(self, ok=True):
+        """Agreement on whether every rank's render succeeded (one 1-element all_reduce, the only collective besides the
+        point-to-point exchange).  A rank whose render failed must not leave its peers waiting in irecv / isend for rows that
+        will never come: callers pass their local status, and when any rank reports failure EVERY rank skips the exchange."""
+        if self.world == 1:
+            return bool(ok)
+        dev = self.band.device if self.band.device.type == "cuda" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def gather(self, ok=None):
+        """Runs the exchange.  ok = this rank's render status (True / False) makes the ranks agree first (all_ok) and raises
+        RuntimeError on every rank if any of them failed; ok = None skips the agreement (the caller vouches for all ranks)."""
+        if ok is not None and not self.all_ok(ok):
+            raise RuntimeError("FrameAssembler.gather: the render failed on " + ("this rank" if not ok else "another rank") + "; exchange skipped on every rank")
         if self.world == 1:
             return self.frame
         ops = []

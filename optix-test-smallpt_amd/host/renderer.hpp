@@ -117,6 +117,25 @@ public:
         const std::vector<spt_sphere> abi = to_abi(spheres);
         check(spt_multi_set_scene(m_, abi.data(), (uint32_t)abi.size()));
     }
+    // the triangle seam and the closest-hit modes on every device (cf. Renderer::setMeshes / setMeshAccel / setSphereAccel)
+    void setMeshes(const std::vector<TriMesh>& meshes, const std::vector<Material>& materials)
+    {
+        if (meshes.size() != materials.size()) throw std::runtime_error("setMeshes: one material per mesh instance");
+        std::vector<spt_mesh> ms(meshes.size());
+        std::vector<spt_material> mats(meshes.size());
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            ms[i].positions = reinterpret_cast<const float*>(meshes[i].positionBuffer.data());
+            ms[i].normals = reinterpret_cast<const float*>(meshes[i].normalBuffer.data());
+            ms[i].indices = meshes[i].indexBuffer.data();
+            ms[i].nverts = (uint32_t)meshes[i].positionBuffer.size();
+            ms[i].ntris = (uint32_t)meshes[i].triangleCount();
+            const Material& m = materials[i];
+            mats[i] = spt_material{{m.emission.x, m.emission.y, m.emission.z}, {m.color.x, m.color.y, m.color.z}, (int32_t)m.refl, 0u};
+        }
+        check(spt_multi_set_meshes(m_, ms.data(), (uint32_t)ms.size(), mats.data()));
+    }
+    void setMeshAccel(int accel) { check(spt_multi_set_mesh_accel(m_, accel)); }
+    void setSphereAccel(int accel) { check(spt_multi_set_sphere_accel(m_, accel)); }
     std::vector<float3> render(const spt_camera& camera, size_t imageWidth, size_t imageHeight,
                                size_t sampleCountPerJitterCell, size_t seed, bool normalise = false)
     {

@@ -243,6 +243,29 @@ class MultiRenderer:
         spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
         self._check(self._lib.spt_multi_set_scene(self._h, spheres.ctypes.data_as(C.c_void_p), len(spheres)))
 
+    def set_meshes(self, meshes, materials):
+        """spt_multi_set_meshes: the triangle scene on every device (see Renderer.set_meshes)."""
+        ms = (SptMesh * max(1, len(meshes)))()
+        mats = (SptMaterial * max(1, len(meshes)))()
+        self._mesh_keepalive = list(meshes)
+        for i, (m, (e, col, refl)) in enumerate(zip(meshes, materials)):
+            ms[i].positions, ms[i].normals, ms[i].indices = m.positions.ctypes.data, m.normals.ctypes.data, m.indices.ctypes.data
+            ms[i].nverts, ms[i].ntris = len(m.positions), len(m.indices)
+            mats[i].emission = (C.c_float * 3)(*[float(v) for v in e])
+            mats[i].color = (C.c_float * 3)(*[float(v) for v in col])
+            mats[i].refl = int(refl)
+        self._check(self._lib.spt_multi_set_meshes(self._h, ms, len(meshes), mats))
+
+    def set_mesh_accel(self, accel):
+        self._check(self._lib.spt_multi_set_mesh_accel(self._h, int(accel)))
+
+    def set_sphere_accel(self, accel):
+        self._check(self._lib.spt_multi_set_sphere_accel(self._h, int(accel)))
+
+    def set_rank_watchdog(self, rank, seconds):
+        """Test hook (csrc/spt_internal.h): kernel watchdog of one rank's context."""
+        self._check(self._lib.spt_multi_set_rank_watchdog(self._h, int(rank), float(seconds)))
+
     def render(self, w, h, samps_per_cell, seed=0, normalise=False, camera=None, to_host=True):
         """Returns ((h, w, 3) float32 image or None, stats dict); with to_host=False the framebuffer stays on the root
         device (``framebuffer_ptr()``)."""

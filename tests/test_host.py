@@ -153,6 +153,38 @@ def test_gloo_world2_row_tiling_matches_single(pkg, oracle, tmp_path, h):
     assert got.shape == (h, w, 3) and np.array_equal(got, ref)
 
 
+def _worker_failure(rank, world, port, w, h, outfile):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from optix_test_smallpt_amd.distributed import FrameAssembler
+    fa = FrameAssembler(w, h, interleave=4)
+    fa.band.fill_(float(rank + 1))
+    verdicts = []
+    for failing in (1, 0, None):                  # rank 1's render fails, then rank 0's, then nobody's
+        try:
+            full = fa.gather(ok=(rank != failing))
+            verdicts.append("ok")
+            if rank == 0:
+                assert float(full.min()) >= 1.0 and float(full.max()) <= float(world)
+        except RuntimeError as e:
+            verdicts.append("this" if "this rank" in str(e) else "other")
+    with open(f"{outfile}.{rank}", "w") as f:
+        f.write(",".join(verdicts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_failed_rank_does_not_hang_the_exchange(tmp_path):
+    """A rank whose render failed reports it through FrameAssembler.gather(ok=False): EVERY rank raises instead of entering the
+    point-to-point exchange (no peer waits for rows that never come), and the next exchange works again."""
+    out = str(tmp_path / "verdict")
+    mp.spawn(_worker_failure, args=(2, _free_port(), 12, 19, out), nprocs=2, join=True)
+    assert open(out + ".0").read() == "other,this,ok"
+    assert open(out + ".1").read() == "this,other,ok"
+
+
 # ------------------------------------------------------------------ host C++ (the reference's language)
 CLI = os.path.join(ROOT, "optix-test-smallpt_amd", "host", "smallpt_mi355x")
 

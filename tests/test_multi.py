@@ -18,7 +18,7 @@ def test_multi_library_exports_header(pkg):
     lib = pkg.load_multi_library()
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     declared = sorted(set(re.findall(r"\b(spt_multi_[a-z_0-9]+)\s*\(", text)))
-    assert len(declared) >= 8 and sorted(pkg.MULTI_SYMBOLS) == declared
+    assert len(declared) >= 11 and sorted(pkg.MULTI_SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name)
     assert C.sizeof(pkg.SptMultiStats) == 48
@@ -94,3 +94,50 @@ def test_several_ranks_on_one_device_assemble_the_same_image(pkg, renderer, rank
         img2, _ = m.render(w, h + 6, samps, seed=seed, normalise=True)             # buffers grow, other partition
         ref2, _ = renderer.render(w, h + 6, samps, seed=seed, normalise=True)
         assert np.array_equal(img2, ref2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["copy3", "self"])
+def test_failed_rank_returns_its_error_and_the_object_stays_usable(pkg, renderer, mode):
+    """One rank's render is made to fail (kernel watchdog of its context at 0.1 us): spt_multi_render must return non-zero with
+    that device's message -- every rank finishes its rows before any part of the exchange is enqueued, so nobody is left waiting in
+    ncclRecv -- and the same object renders the correct image once the watchdog is lifted.  Three ranks sharing device 0 (copy
+    transport) and one rank whose band goes through RCCL (grouped self send/recv)."""
+    w, h, samps, seed = 64, 50, 2, 5
+    sc = pkg.cornell9()
+    renderer.set_scene(sc)
+    ref, rst = renderer.render(w, h, samps, seed=seed, normalise=True)
+    kw = dict(copy_exchange=True) if mode == "copy3" else dict(self_exchange=True)
+    ids, bad = ((0, 0, 0), 1) if mode == "copy3" else ((0,), 0)
+    with pkg.MultiRenderer(ids, **kw) as m:
+        m.set_scene(sc)
+        m.set_rank_watchdog(bad, 1e-7)
+        with pytest.raises(pkg.SptError, match="watchdog"):
+            m.render(w, h, samps, seed=seed, normalise=True)
+        m.set_rank_watchdog(bad, 60.0)
+        img, st = m.render(w, h, samps, seed=seed, normalise=True)
+        assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+
+
+@pytest.mark.gpu
+def test_multi_mesh_scene_and_accel_pass_throughs(pkg, renderer):
+    """spt_multi_set_meshes / set_mesh_accel / set_sphere_accel: the triangle scene the reference ships and a large sphere table
+    over three ranks sharing the device -- the same images as the single-context renderer."""
+    meshes, mats = pkg.single_triangle_scene()
+    cam = pkg.pinhole_camera()
+    renderer.set_meshes(meshes, mats)
+    ref, _ = renderer.render(48, 36, 1, seed=2, camera=cam)
+    big = pkg.random_spheres(300, 5)
+    with pkg.MultiRenderer((0, 0, 0), copy_exchange=True) as m:
+        m.set_mesh_accel(pkg.ACCEL_BVH)
+        m.set_meshes(meshes, mats)
+        img, _ = m.render(48, 36, 1, seed=2, camera=cam)
+        assert np.array_equal(img, ref)
+        for accel in (pkg.ACCEL_GRID, pkg.ACCEL_BVH, pkg.ACCEL_EXHAUSTIVE):
+            m.set_sphere_accel(accel)
+            m.set_scene(big)
+            img, st = m.render(40, 33, 1, seed=3, normalise=True)
+            renderer.set_scene(big)
+            ref2, rst = renderer.render(40, 33, 1, seed=3, normalise=True)
+            assert np.array_equal(img, ref2) and st["bounces"] == rst["bounces"], accel
+    renderer.set_scene(pkg.cornell9())
