@@ -97,7 +97,19 @@ def interactive(pkg, r, dev, frames=600):
     prog2.flush()
     dt2 = (time.perf_counter() - t0) / frames
     prog2.close()
-    return {"workload": f"Cornell-9, {w}x{h}, 4 spp per frame (1 per jitter cell), pinhole camera + box-in-cell sampling, "
+    # the product's own host: the C++ render loop (host/viewer.cpp, spt_progressive_frame / _frame_async behind the C-ABI) through the CLI
+    cpp = {}
+    cli = os.path.join(ROOT, "optix-test-smallpt_amd", "host", "smallpt_mi355x")
+    if os.path.exists(cli):
+        import subprocess
+        for lanes in (1, 2):
+            try:
+                o = subprocess.run([cli, "4", "--viewer", "--size", f"{w}x{h}", "--org", "50,45,168", "--pipeline", str(lanes), "--bench-frames", str(frames)],
+                                   capture_output=True, text=True, timeout=300)
+                cpp[f"frames_per_s_cpp_pipeline{lanes}"] = json.loads(o.stdout.strip().splitlines()[-1])["frames_per_s"] if o.returncode == 0 else None
+            except Exception:
+                cpp[f"frames_per_s_cpp_pipeline{lanes}"] = None
+    return {**cpp, "workload": f"Cornell-9, {w}x{h}, 4 spp per frame (1 per jitter cell), pinhole camera + box-in-cell sampling, "
                         f"frame accumulated in HBM, {frames} frames", "frames_per_s": round(1.0 / dt, 1),
             "frames_per_s_two_in_flight": round(1.0 / dt2, 1),
             "kernel_ms": round(sum(kms) / len(kms), 4), "finalize_ms": round(sum(fms) / len(fms), 4),

@@ -214,6 +214,23 @@ int  spt_progressive_begin(spt_ctx* ctx, uint32_t w, uint32_t h);
 int  spt_progressive_frame(spt_ctx* ctx, const spt_camera* cam, uint32_t samps_per_cell, uint64_t seed, int clear, spt_stats* stats);
 int  spt_progressive_snapshot(spt_ctx* ctx, float* out_rgb);
 int  spt_progressive_end(spt_ctx* ctx);
+/* The same loop with SEVERAL FRAMES IN FLIGHT.  The reference overlaps its render thread with the GL thread (smallpt.cpp:895-962);
+ * on the GPU the end of a 4-spp frame is a handful of long specular chains that leave most of the chip idle, so a host that
+ * issues frame k+1 before frame k has drained keeps it busy.  A context renders one frame at a time (its scratch buffers belong
+ * to the frame), hence one context per frame in flight:
+ *   spt_progressive_attach(lane, owner)   `lane` (another context on the same device, with the same scene) gets its own frame
+ *                            buffer of the owner's size and a stream whose priority differs from the owner's (equal-priority
+ *                            streams of a process share a hardware queue and would serialise the frames);
+ *   spt_progressive_frame_async(lane, owner, cam, samps, seed, clear)   enqueues render + accumulation on the lane's stream and
+ *                            returns without waiting.  `lane` may be the owner itself.  The accumulations into the owner's
+ *                            accumBuffer run in the order of the calls (chained by events), so accumBuffer is bit-identical
+ *                            to the blocking loop's; the lane's previous frame must have been waited for;
+ *   spt_progressive_wait(lane, stats)     waits for the lane's frame in flight (render and accumulation);
+ *   spt_progressive_snapshot(owner, ...)  waits for every accumulation issued so far, then copies.
+ * One host thread drives all lanes of an owner (contexts are not thread-safe). */
+int  spt_progressive_attach(spt_ctx* lane, spt_ctx* owner);
+int  spt_progressive_frame_async(spt_ctx* lane, spt_ctx* owner, const spt_camera* cam, uint32_t samps_per_cell, uint64_t seed, int clear);
+int  spt_progressive_wait(spt_ctx* lane, spt_stats* stats);
 
 /* Waits for the last launch of this context and fills stats (may be NULL). */
 int  spt_sync(spt_ctx* ctx, spt_stats* stats);

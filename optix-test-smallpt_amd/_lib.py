@@ -63,6 +63,9 @@ SYMBOLS = {
     "spt_progressive_begin": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "spt_progressive_frame": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint64, C.c_int, C.POINTER(SptStats)]),
     "spt_progressive_snapshot": (C.c_int, [_P, _P]),
+    "spt_progressive_attach": (C.c_int, [_P, _P]),
+    "spt_progressive_frame_async": (C.c_int, [_P, _P, C.POINTER(SptCamera), C.c_uint32, C.c_uint64, C.c_int]),
+    "spt_progressive_wait": (C.c_int, [_P, C.POINTER(SptStats)]),
     "spt_progressive_end": (C.c_int, [_P]),
     "spt_sync": (C.c_int, [_P, C.POINTER(SptStats)]),
     "spt_to_int": (C.c_int, [C.c_float]),

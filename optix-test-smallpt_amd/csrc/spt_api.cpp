@@ -77,6 +77,9 @@ struct spt_ctx {
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
     float* d_frame = nullptr;
     uint32_t prog_w = 0, prog_h = 0;
+    hipEvent_t ev_acc = nullptr;   // owner of an accumBuffer: completion of the most recent accumulation (any lane's stream)
+    bool acc_recorded = false;
+    bool frame_in_flight = false;  // a spt_progressive_frame_async of this lane has not been waited for
     unsigned long long pool_stats[24] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
@@ -199,6 +202,7 @@ void spt_destroy(spt_ctx* c)
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_acc) (void)hipEventDestroy(c->ev_acc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -981,11 +985,15 @@ int spt_progressive_end(spt_ctx* c)
 {
     if (!c) return 1;
     SPT_HIP(c, hipSetDevice(c->device));
+    if (c->stream) SPT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
+    if (c->acc_recorded) SPT_HIP(c, hipEventSynchronize(c->ev_acc));   // accumulations other lanes still have in flight
     if (c->d_accum) (void)hipFree(c->d_accum);
     if (c->d_frame) (void)hipFree(c->d_frame);
     c->d_accum = c->d_frame = nullptr;
     c->prog_w = c->prog_h = 0;
+    c->acc_recorded = false;
+    c->frame_in_flight = false;
     return 0;
 }
 
@@ -998,19 +1006,64 @@ int spt_progressive_begin(spt_ctx* c, uint32_t w, uint32_t h)
     SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_accum), bytes));
     SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_frame), bytes));
     SPT_HIP(c, hipMemsetAsync(c->d_accum, 0, bytes, c->stream));       // accumBuffer.resize(w*h, make_float3(0,0,0)), :882
+    if (!c->ev_acc) SPT_HIP(c, hipEventCreateWithFlags(&c->ev_acc, hipEventDisableTiming));
+    SPT_HIP(c, hipEventRecord(c->ev_acc, c->stream));                  // later accumulations (any lane) run behind the clearing
+    c->acc_recorded = true;
     c->prog_w = w; c->prog_h = h;
     return 0;
+}
+
+int spt_progressive_attach(spt_ctx* lane, spt_ctx* owner)
+{
+    if (!lane || !owner) return 1;
+    if (lane == owner) return 0;
+    if (!owner->d_accum) return lane->fail("spt_progressive_attach: call spt_progressive_begin on the owner first");
+    if (lane->device != owner->device) return lane->fail("spt_progressive_attach: lane and owner are on different devices");
+    if (int rc = spt_progressive_end(lane)) return rc;
+    SPT_HIP(lane, hipSetDevice(lane->device));
+    // a stream of another priority than the owner's (created at the default priority by spt_create)
+    int lo = 0, hi = 0;
+    SPT_HIP(lane, hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = numerically largest = lowest priority
+    if (lane->stream) { (void)hipStreamSynchronize(lane->stream); (void)hipStreamDestroy(lane->stream); lane->stream = nullptr; }
+    SPT_HIP(lane, hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, hi));
+    SPT_HIP(lane, hipMalloc(reinterpret_cast<void**>(&lane->d_frame), (size_t)owner->prog_w * owner->prog_h * 3 * sizeof(float)));
+    lane->prog_w = owner->prog_w; lane->prog_h = owner->prog_h;
+    return 0;
+}
+
+int spt_progressive_frame_async(spt_ctx* c, spt_ctx* owner, const spt_camera* cam, uint32_t samps, uint64_t seed, int clear)
+{
+    if (!c || !owner) return 1;
+    if (!owner->d_accum) return c->fail("spt_progressive_frame_async: call spt_progressive_begin on the owner first");
+    if (!c->d_frame || c->prog_w != owner->prog_w || c->prog_h != owner->prog_h)
+        return c->fail("spt_progressive_frame_async: call spt_progressive_attach(lane, owner) first");
+    if (c->frame_in_flight) return c->fail("spt_progressive_frame_async: the lane's previous frame has not been waited for");
+    // :922 the frame is the UN-NORMALISED sum of Renderer::render, on the lane's stream
+    if (int rc = spt_render_rows_device(c, cam, c->prog_w, c->prog_h, 0, c->prog_h, samps, seed, 0u, c->d_frame, nullptr)) return rc;
+    // :927-937 accumBuffer (clear ? = : +=) outImage, behind the previous accumulation whichever lane issued it
+    if (owner->acc_recorded) SPT_HIP(c, hipStreamWaitEvent(c->stream, owner->ev_acc, 0));
+    SPT_HIP(c, spt_k_accumulate(owner->d_accum, c->d_frame, (size_t)c->prog_w * c->prog_h * 3, clear, c->stream));
+    SPT_HIP(c, hipEventRecord(owner->ev_acc, c->stream));
+    owner->acc_recorded = true;
+    c->frame_in_flight = true;
+    return 0;
+}
+
+int spt_progressive_wait(spt_ctx* c, spt_stats* stats)
+{
+    if (!c) return 1;
+    SPT_HIP(c, hipSetDevice(c->device));
+    SPT_HIP(c, hipStreamSynchronize(c->stream));
+    c->frame_in_flight = false;
+    return spt_sync(c, stats);
 }
 
 int spt_progressive_frame(spt_ctx* c, const spt_camera* cam, uint32_t samps, uint64_t seed, int clear, spt_stats* stats)
 {
     if (!c) return 1;
     if (!c->d_accum) return c->fail("spt_progressive_frame: call spt_progressive_begin first");
-    // :922 the frame is the UN-NORMALISED sum of Renderer::render; :927-937 accumBuffer (clear ? = : +=) outImage
-    if (int rc = spt_render_rows_device(c, cam, c->prog_w, c->prog_h, 0, c->prog_h, samps, seed, 0u, c->d_frame, nullptr)) return rc;
-    if (int rc = spt_accumulate_device(c, c->d_accum, c->d_frame, (uint64_t)c->prog_w * c->prog_h * 3, clear, nullptr)) return rc;
-    SPT_HIP(c, hipStreamSynchronize(c->stream));
-    return spt_sync(c, stats);
+    if (int rc = spt_progressive_frame_async(c, c, cam, samps, seed, clear)) return rc;
+    return spt_progressive_wait(c, stats);
 }
 
 int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
@@ -1018,6 +1071,7 @@ int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
     if (!c) return 1;
     if (!c->d_accum || !out_rgb) return c->fail("spt_progressive_snapshot: no accumulation buffer or out_rgb is NULL");
     SPT_HIP(c, hipSetDevice(c->device));
+    if (c->acc_recorded) SPT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_acc, 0));   // every accumulation issued so far, any lane
     SPT_HIP(c, hipMemcpyAsync(out_rgb, c->d_accum, (size_t)c->prog_w * c->prog_h * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     SPT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;

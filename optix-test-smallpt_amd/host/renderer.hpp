@@ -52,6 +52,13 @@ public:
     {
         check(spt_progressive_frame(ctx_, &camera, (uint32_t)sampleCountPerJitterCell, (uint64_t)seed, clear ? 1 : 0, &stats_));
     }
+    // several frames in flight (spt_progressive_attach / _frame_async / _wait): this context as a lane of `owner`'s accumBuffer
+    void progressiveAttach(Renderer& owner) { check(spt_progressive_attach(ctx_, owner.ctx_)); }
+    void progressiveFrameAsync(Renderer& owner, const spt_camera& camera, size_t sampleCountPerJitterCell, size_t seed, bool clear)
+    {
+        check(spt_progressive_frame_async(ctx_, owner.ctx_, &camera, (uint32_t)sampleCountPerJitterCell, (uint64_t)seed, clear ? 1 : 0));
+    }
+    void progressiveWait() { check(spt_progressive_wait(ctx_, &stats_)); }
     void progressiveSnapshot(std::vector<float3>& image) { check(spt_progressive_snapshot(ctx_, reinterpret_cast<float*>(image.data()))); }
     void progressiveEnd() { check(spt_progressive_end(ctx_)); }
 

@@ -5,9 +5,10 @@
 //
 //   smallpt_mi355x [spp] [--scene file.json | shipped-meshes] [--size WxH] [--seed N] [--out image.ppm] [--device D]
 //                  [--dump-scene out.json] [--parse-only]
-//                  [--accel bvh|exhaustive]                    mesh scenes / sphere tables above 24: hierarchy or every primitive (default)
+//                  [--accel grid|bvh|exhaustive]               closest hit of sphere tables above 24 (default grid) / mesh scenes (default exhaustive)
 //                  [--devices 0,1,...] [--self-exchange]      row bands over several GPUs + RCCL exchange (MultiRenderer)
 //   smallpt_mi355x [spp] --viewer [--frames N] [--request JSON] [--frames-after M] [--threaded] [--org x,y,z]
+//                  [--pipeline L] [--bench-frames N]           L frames in flight (one context each); frames/s of N frames as JSON
 //                  [--dump-raw accum.bin]                      main()'s progressive loop (smallpt.cpp:840-1005) without the
 //                                                              window: N frames, then the request(s), then M frames; writes the
 //                                                              normalised image like the exit path (:995-1004)
@@ -16,11 +17,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "renderer.hpp"
+#include "../csrc/spt_internal.h"
 #include "viewer.hpp"
 
 using namespace spt_host;
@@ -29,7 +32,9 @@ int main(int argc, char* argv[])
 {
     int spp = 4, w = 256, h = 256, device = 0;       // smallpt.cpp:274-276 defaults
     unsigned long long seed = 0;
-    int accel = SPT_ACCEL_EXHAUSTIVE;
+    int accel = -1;                                  // -1: the library's defaults (spheres: grid; meshes: exhaustive)
+    int pipeline = 1, bench_frames = 0;
+    double watchdog = 0.0;                           // test hook: kernel watchdog in seconds (csrc/spt_internal.h)
     std::string scene_path, out_path = "image.ppm", dump_path;
     bool single_triangle = false;
     bool parse_only = false, viewer = false, threaded = false, self_exchange = false;
@@ -57,7 +62,10 @@ int main(int argc, char* argv[])
                 return 0;
             } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
         }
-        else if (a == "--accel") { const std::string m = next(); if (m == "bvh") accel = SPT_ACCEL_BVH; else if (m == "exhaustive") accel = SPT_ACCEL_EXHAUSTIVE; else { std::fprintf(stderr, "--accel bvh|exhaustive\n"); return 2; } }
+        else if (a == "--accel") { const std::string m = next(); if (m == "bvh") accel = SPT_ACCEL_BVH; else if (m == "exhaustive") accel = SPT_ACCEL_EXHAUSTIVE; else if (m == "grid") accel = SPT_ACCEL_GRID; else { std::fprintf(stderr, "--accel grid|bvh|exhaustive\n"); return 2; } }
+        else if (a == "--pipeline") { pipeline = std::atoi(next()); if (pipeline < 1 || pipeline > 4) { std::fprintf(stderr, "--pipeline 1..4\n"); return 2; } }
+        else if (a == "--bench-frames") bench_frames = std::atoi(next());
+        else if (a == "--watchdog") watchdog = std::atof(next());
         else if (a == "--single-triangle") single_triangle = true;   // SingleTriangleScene of main(), smallpt.cpp:818-832
         else if (a == "--viewer") viewer = true;
         else if (a == "--threaded") threaded = true;
@@ -75,8 +83,9 @@ int main(int argc, char* argv[])
         Scene scene = scene_path.empty() ? cornell9() : (scene_path == "shipped-meshes" ? shipped_two_sphere_mesh_scene() : load_scene_file(scene_path));
         realize_meshes(scene);
         auto upload = [&](Renderer& rr) {          // spheres, or the Intersector seam for a mesh scene
-            if (scene.meshes.empty()) { rr.setSphereAccel(accel); rr.setScene(scene.spheres); return; }
-            rr.setMeshAccel(accel);
+            if (scene.meshes.empty()) { if (accel >= 0) rr.setSphereAccel(accel); rr.setScene(scene.spheres); return; }
+            if (accel == SPT_ACCEL_GRID) throw std::runtime_error("--accel grid applies to sphere scenes");
+            if (accel >= 0) rr.setMeshAccel(accel);
             std::vector<TriMesh> ms; std::vector<Material> mats;
             for (const MeshInstance& m : scene.meshes) { ms.push_back(m.mesh); mats.push_back(m.material); }
             rr.setMeshes(ms, mats);
@@ -94,32 +103,49 @@ int main(int argc, char* argv[])
         if (viewer) {
             // main() of the reference (smallpt.cpp:840-1005) without GLFW/GL: render thread + request queue + accumulation
             Renderer renderer(device);
-            if (single_triangle) {
+            std::vector<std::unique_ptr<Renderer>> extra;           // --pipeline N: one more context (same device, same scene) per further frame in flight
+            for (int k = 1; k < pipeline; ++k) extra.emplace_back(new Renderer(device));
+            auto setup = [&](Renderer& rr, bool probe_it) {
+                if (!single_triangle) { upload(rr); return; }
                 TriMesh triangle;                                                     // smallpt.cpp:826-828
                 triangle.positionBuffer = {make_float3(-0.5f, -0.5f, -2), make_float3(0.5f, -0.5f, -2), make_float3(0, 0.5f, -2)};
                 triangle.normalBuffer = {make_float3(1, 0, 0), make_float3(0, 1, 0), make_float3(0, 0, 1)};
                 triangle.indexBuffer = {0, 1, 2};
-                renderer.setMeshes({triangle}, {Material{make_float3(1, 0, 0), make_float3(0, 0, 0), DIFF}});   // :821, :830-831
+                rr.setMeshes({triangle}, {Material{make_float3(1, 0, 0), make_float3(0, 0, 0), DIFF}});   // :821, :830-831
+                if (!probe_it) return;
                 const Ray probe{make_float3(0, 0, 0), make_float3(0, 0, -1)};
-                const std::vector<Hit> hit = renderer.traceRays(&probe, 1);
+                const std::vector<Hit> hit = rr.traceRays(&probe, 1);
                 std::fprintf(stderr, "traceRays probe: dist %.9g uv (%.9g, %.9g) hit %d\n", hit[0].dist, hit[0].uv[0], hit[0].uv[1], (int)(bool)hit[0]);
-            } else {
-                upload(renderer);
-            }
+            };
+            setup(renderer, true);
+            if (watchdog > 0) spt_set_watchdog(renderer.handle(), watchdog);
+            std::vector<Renderer*> lanes;
+            for (auto& e : extra) { setup(*e, false); lanes.push_back(e.get()); }
             Camera camera = defaultViewerCamera();
             if (have_org) camera.org = make_float3(org[0], org[1], org[2]);
-            ProgressiveRenderer prog(renderer, (size_t)w, (size_t)h, (size_t)samps, camera);
+            ProgressiveRenderer prog(renderer, (size_t)w, (size_t)h, (size_t)samps, camera, lanes);
             auto run_frames = [&](int n) {
                 if (n <= 0) return;
                 if (threaded) {
                     const size_t target = prog.framesRendered() + (size_t)n;
                     prog.start();
-                    while (prog.framesRendered() < target) std::this_thread::yield();
+                    while (prog.framesRendered() < target && prog.lastError().empty()) std::this_thread::yield();
                     prog.stop();
+                    if (!prog.lastError().empty()) throw std::runtime_error("render thread: " + prog.lastError());
                 } else {
                     for (int k = 0; k < n; ++k) prog.stepOnce();
                 }
             };
+            if (bench_frames > 0) {      // frames per second of the loop (warm-up 10 frames), for bench.py's interactive row
+                for (int k = 0; k < 10; ++k) prog.stepOnce();
+                prog.flush();
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int k = 0; k < bench_frames; ++k) prog.stepOnce();
+                prog.flush();
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                std::printf("{\"frames\": %d, \"pipeline\": %d, \"width\": %d, \"height\": %d, \"spp_per_frame\": %d, \"frames_per_s\": %.1f}\n", bench_frames, pipeline, w, h, 4 * samps, bench_frames / dt);
+                return 0;
+            }
             run_frames(frames);
             for (const std::string& r : requests) prog.postRequest(r);
             run_frames(frames_after);

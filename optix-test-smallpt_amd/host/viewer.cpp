@@ -24,15 +24,24 @@ Camera defaultViewerCamera()
 
 bool parseUpdateCamera(const std::string& json, float3* org) { return parse_update_camera_request(json, org); }
 
-ProgressiveRenderer::ProgressiveRenderer(Renderer& renderer, size_t imageWidth, size_t imageHeight, size_t sampleCountPerJitterCell, const Camera& camera)
+ProgressiveRenderer::ProgressiveRenderer(Renderer& renderer, size_t imageWidth, size_t imageHeight, size_t sampleCountPerJitterCell, const Camera& camera,
+                                         const std::vector<Renderer*>& extraLanes)
     : renderer_(renderer), w_(imageWidth), h_(imageHeight), samps_(sampleCountPerJitterCell), camera_(camera), org_(camera.org)
 {
     renderer_.progressiveBegin(w_, h_);             // accumBuffer.resize(w*h, 0), :881-883
+    lanes_.push_back(&renderer_);
+    for (Renderer* r : extraLanes) {
+        r->progressiveAttach(renderer_);            // own frame buffer + a stream of another priority
+        lanes_.push_back(r);
+    }
+    inFlight_.assign(lanes_.size(), 0);
 }
 
 ProgressiveRenderer::~ProgressiveRenderer()
 {
     stop();
+    try { flush(); } catch (...) {}
+    for (size_t i = 1; i < lanes_.size(); ++i) { try { lanes_[i]->progressiveEnd(); } catch (...) {} }
     try { renderer_.progressiveEnd(); } catch (...) {}
 }
 
@@ -40,7 +49,17 @@ void ProgressiveRenderer::start()
 {
     if (thread_.joinable()) return;
     renderDone_ = false;
-    thread_ = std::thread([this] { while (!renderDone_) stepOnce(); });   // :895-901
+    thread_ = std::thread([this] {                   // :895-901
+        // an exception must not leave the thread (std::terminate): keep its message, end the loop
+        try {
+            while (!renderDone_) stepOnce();
+            flush();
+        } catch (const std::exception& e) {
+            std::unique_lock<std::mutex> l{requestsMutex_};
+            lastError_ = e.what();
+            renderDone_ = true;
+        }
+    });
 }
 
 void ProgressiveRenderer::stop()
@@ -49,8 +68,23 @@ void ProgressiveRenderer::stop()
     if (thread_.joinable()) thread_.join();          // :993
 }
 
+std::string ProgressiveRenderer::lastError()
+{
+    std::unique_lock<std::mutex> l{requestsMutex_};
+    return lastError_;
+}
+
+void ProgressiveRenderer::flush()
+{
+    std::unique_lock<std::mutex> l{accumMutex_};
+    for (size_t i = 0; i < lanes_.size(); ++i)
+        if (inFlight_[i]) { inFlight_[i] = 0; lanes_[i]->progressiveWait(); }
+}
+
 void ProgressiveRenderer::postRequest(const std::string& json)
 {
+    float3 ignored;
+    (void)parseUpdateCamera(json, &ignored);         // malformed text is refused HERE, on the caller's thread, not in the render thread
     std::unique_lock<std::mutex> l{requestsMutex_};  // :980
     requests_.emplace_back(json);
 }
@@ -84,7 +118,14 @@ void ProgressiveRenderer::stepOnce()
     }
     // :922 render + :927-937 accumulate, both on the device; the lock keeps a snapshot from reading a half-added frame
     std::unique_lock<std::mutex> l{accumMutex_};     // :925
-    renderer_.progressiveFrame(camera_.abi(), samps_, seed, needClearBuffer);
+    if (lanes_.size() == 1) {
+        renderer_.progressiveFrame(camera_.abi(), samps_, seed, needClearBuffer);
+    } else {
+        const size_t k = issued_++ % lanes_.size();  // frame in flight on lane k: wait for the one it rendered before, issue, return
+        if (inFlight_[k]) { inFlight_[k] = 0; lanes_[k]->progressiveWait(); }
+        lanes_[k]->progressiveFrameAsync(renderer_, camera_.abi(), samps_, seed, needClearBuffer);
+        inFlight_[k] = 1;
+    }
     ++sampleCount_;                                  // :926
     if (needClearBuffer) sampleCount_ = 1;           // :938-939
     ++framesRendered_;

@@ -12,6 +12,12 @@
 //
 // accumBuffer lives in HBM (spt_progressive_*); the mutex guards the frame counter and the request queue like the
 // reference's two mutexes, and serialises the snapshot against a frame in flight.
+//
+// Two frames in flight: the reference overlaps rendering with display (:895-962); on the GPU the end of a 4-spp frame is a few
+// long specular chains that leave most of the chip idle, so with extra lanes (further Renderer contexts holding the same scene)
+// stepOnce() issues frame k on lane k % lanes without waiting for frame k-1 (spt_progressive_frame_async): the accumulations stay
+// in frame order, accumBuffer is bit-identical to the serial loop's, a camera request still replaces the buffer with the frame
+// rendered at the running sampleCount (:922-939).
 #pragma once
 #include <atomic>
 #include <mutex>
@@ -40,14 +46,18 @@ bool parseUpdateCamera(const std::string& json, float3* org);
 
 class ProgressiveRenderer {
 public:
-    ProgressiveRenderer(Renderer& renderer, size_t imageWidth, size_t imageHeight, size_t sampleCountPerJitterCell, const Camera& camera);
+    // extraLanes: further contexts on the same device with the same scene, one per additional frame in flight
+    ProgressiveRenderer(Renderer& renderer, size_t imageWidth, size_t imageHeight, size_t sampleCountPerJitterCell, const Camera& camera,
+                        const std::vector<Renderer*>& extraLanes = {});
     ~ProgressiveRenderer();
 
     void start();                                   // spawns the render thread (:895)
     void stop();                                    // renderDone = true; join (:992-993)
     void stepOnce();                                // one iteration of the thread's while-body (:903-941)
 
-    void postRequest(const std::string& json);      // GL thread side, :978-985
+    void postRequest(const std::string& json);      // GL thread side, :978-985; throws std::runtime_error on malformed JSON (caller's thread)
+    void flush();                                   // waits for every frame in flight
+    std::string lastError();                        // message of the exception that ended the render thread ("" if none)
     void moveCamera(float dy);                      // keys UP (+0.01) / DOWN (-0.01), :968-985
 
     // :955-959: copies accumBuffer and returns the display weight in weight3 (all three equal, :961)
@@ -58,6 +68,10 @@ public:
 
 private:
     Renderer& renderer_;
+    std::vector<Renderer*> lanes_;                  // lanes_[0] = &renderer_ (owner of accumBuffer)
+    std::vector<char> inFlight_;
+    size_t issued_ = 0;
+    std::string lastError_;
     size_t w_, h_, samps_;
     Camera camera_;            // render-thread copy (:899)
     float3 org_;               // GL-thread copy moved by the keys (:887)

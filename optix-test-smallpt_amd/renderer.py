@@ -63,6 +63,10 @@ class Renderer:
         self._h = h
         self.device_id = int(device_id)
         self._scene = None
+        # everything a second context needs to render the same frames (ProgressiveRenderer(pipeline=2) replays it on its extra
+        # lane): the current scene (sphere table or meshes + materials), the closest-hit modes, tuning and watchdog
+        self._state = {"scene": None, "sphere_accel": None, "mesh_accel": None, "tuning": None, "watchdog": None}
+        self._state_version = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -89,6 +93,25 @@ class Renderer:
         spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
         self._scene = spheres
         self._check(self._lib.spt_set_scene(self._h, spheres.ctypes.data_as(C.c_void_p), len(spheres)))
+        self._state["scene"] = ("spheres", spheres)
+        self._state_version += 1
+
+    def replay_state_on(self, other):
+        """Brings another context (same device) to this one's scene, closest-hit modes, tuning and watchdog."""
+        st = self._state
+        if st["tuning"] is not None:
+            other.set_tuning(*st["tuning"])
+        if st["watchdog"] is not None:
+            other.set_watchdog(st["watchdog"])
+        if st["sphere_accel"] is not None:
+            other.set_sphere_accel(st["sphere_accel"])
+        if st["mesh_accel"] is not None:
+            other.set_mesh_accel(st["mesh_accel"])
+        if st["scene"] is not None:
+            if st["scene"][0] == "spheres":
+                other.set_scene(st["scene"][1])
+            else:
+                other.set_meshes(st["scene"][1], st["scene"][2])
 
     def set_meshes(self, meshes, materials):
         """Intersector::addTriangleMesh for every TriMesh + build() (smallpt.cpp:437-447); materials[i] = (emission, color,
@@ -105,16 +128,23 @@ class Renderer:
             mats[i].color = (C.c_float * 3)(*[float(v) for v in col])
             mats[i].refl = int(refl)
         self._check(self._lib.spt_set_meshes(self._h, ms, len(meshes), mats))
+        self._scene = None                                   # the sphere table is no longer the current scene
+        self._state["scene"] = ("meshes", list(meshes), list(materials))
+        self._state_version += 1
 
     def set_sphere_accel(self, accel):
         """How sphere tables above 24 spheres find their closest hit: ACCEL_GRID (default: uniform grid in LDS), ACCEL_BVH (hierarchy) --
         both exhaustive-equivalent by construction (include/smallpt_mi355x.h) -- or ACCEL_EXHAUSTIVE."""
         self._check(self._lib.spt_set_sphere_accel(self._h, int(accel)))
+        self._state["sphere_accel"] = int(accel)
+        self._state_version += 1
 
     def set_mesh_accel(self, accel):
         """ACCEL_EXHAUSTIVE (default: every triangle, bit-identical to the reference's loops) or ACCEL_BVH (the role of the
         reference's OptiX Prime model, smallpt.cpp:475-603; contract in include/smallpt_mi355x.h)."""
         self._check(self._lib.spt_set_mesh_accel(self._h, int(accel)))
+        self._state["mesh_accel"] = int(accel)
+        self._state_version += 1
 
     def trace_rays(self, rays):
         """Intersector::traceRays (smallpt.cpp:460-470): rays = array of RAY_DTYPE (or (n, 6) floats); returns HIT_DTYPE[n]."""
@@ -127,6 +157,8 @@ class Renderer:
 
     def set_tuning(self, blocks_per_cu=0, variant=0):
         self._check(self._lib.spt_set_tuning(self._h, blocks_per_cu, variant))
+        self._state["tuning"] = (int(blocks_per_cu), int(variant))
+        self._state_version += 1
 
     def render(self, w, h, samps_per_cell, seed=0, normalise=False, camera=None):
         """Full image to host memory: (h, w, 3) float32, row 0 = bottom.  Returns (image, stats)."""
@@ -161,6 +193,8 @@ class Renderer:
     def set_watchdog(self, seconds):
         """Pool kernel: a launch whose waves run longer than this fails in sync() instead of hanging (0 = off)."""
         self._check(self._lib.spt_set_watchdog(self._h, float(seconds)))
+        self._state["watchdog"] = float(seconds)
+        self._state_version += 1
 
     def last_kernel(self):
         """'pool' (spt_pool.hip, material-sorted), 'mega' (spt_kernel.hip), 'mesh' (spt_mesh.hip, triangles), 'sbvh' (spt_mesh.hip over a
@@ -308,9 +342,9 @@ class ProgressiveRenderer:
         self._lanes = []
         for i in range(self.pipeline):
             rr = renderer if i == 0 else Renderer(renderer.device_id)
-            if i and renderer._scene is not None:
-                rr.set_scene(renderer._scene)
-            self._lanes.append({"r": rr, "frame": torch.empty((h, w, 3), dtype=torch.float32, device=dev),
+            if i:
+                renderer.replay_state_on(rr)              # spheres OR meshes + materials, closest-hit modes, tuning, watchdog
+            self._lanes.append({"r": rr, "version": renderer._state_version, "frame": torch.empty((h, w, 3), dtype=torch.float32, device=dev),
                                 # alternate stream priorities: HIP maps equal-priority streams of a process onto a shared hardware queue,
                                 # which would serialise the two frames
                                 "stream": torch.cuda.current_stream(dev) if self.pipeline == 1 else torch.cuda.Stream(dev, priority=-(i % 2)),
@@ -328,6 +362,11 @@ class ProgressiveRenderer:
         lane = self._lanes[self._issued % self.pipeline]
         self._issued += 1
         r, stream = lane["r"], lane["stream"]
+        if r is not self.r and lane["version"] != self.r._state_version:      # the primary's scene / modes changed since this lane was set up
+            lane["stream"].synchronize()
+            r.sync()
+            self.r.replay_state_on(r)
+            lane["version"] = self.r._state_version
         seed = self.frames       # :922 renders with the running sampleCount, also on the clearing frame
         if self.pipeline > 1 and lane["done"] is not None:
             stream.wait_event(lane["done"])               # the lane's frame buffer was read by its last accumulation

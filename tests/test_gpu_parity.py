@@ -164,6 +164,42 @@ def test_pipelined_progressive_accumulation_is_bit_identical(pkg, renderer):
     assert np.array_equal(results[0][0], results[1][0]) and results[0][0].max() > 0
 
 
+def test_pipelined_progressive_loop_mirrors_mesh_scenes_and_scene_changes(pkg, renderer):
+    """The extra lane of ProgressiveRenderer(pipeline=2) must render what the primary renders: a mesh scene (the primary's sphere
+    table is stale then), its closest-hit mode, and a scene set AFTER the lanes were created."""
+    w, h, samps = 64, 36, 1
+    meshes, mats = pkg.single_triangle_scene()
+    cam = pkg.pinhole_camera()
+    try:
+        renderer.set_scene(pinhole_scene(pkg))               # leaves a sphere table behind ...
+        renderer.set_mesh_accel(pkg.ACCEL_BVH)
+        renderer.set_meshes(meshes, mats)                    # ... which is no longer the current scene
+        accs = []
+        for pipeline in (1, 2):
+            prog = pkg.ProgressiveRenderer(renderer, w, h, samps, camera=cam, pipeline=pipeline)
+            for _ in range(4):
+                prog.step()
+            prog.flush()
+            accs.append(prog.accum.cpu().numpy().copy())
+            if pipeline == 2:                                # scene change after construction: both lanes follow
+                renderer.set_scene(pinhole_scene(pkg))
+                prog.update_camera(cam)
+                for _ in range(4):
+                    prog.step()
+                prog.flush()
+                after = prog.accum.cpu().numpy().copy()
+            prog.close()
+        assert np.array_equal(accs[0], accs[1]) and accs[0].max() > 0
+        serial = pkg.ProgressiveRenderer(renderer, w, h, samps, camera=cam)      # the sphere scene, serial loop: frames 4 (clearing), 1, 2, 3
+        serial.frames = 4
+        for _ in range(4):
+            serial.step()
+        assert np.array_equal(serial.accum.cpu().numpy(), after)
+    finally:
+        renderer.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
+        renderer.set_scene(pkg.cornell9())
+
+
 def test_monte_carlo_convergence(pkg, renderer):
     """Estimator sanity on the GPU path: images from independent seeds agree within Monte-Carlo noise, and the
     noise falls like 1/sqrt(spp) (a biased RNG stream or a broken roulette compensation would not)."""

@@ -50,6 +50,55 @@ def test_render_thread_requests_and_snapshot(pkg, oracle, tmp_path):
     assert ppm.read_bytes() == expected_ppm(oracle, (f2 + f1) * weight)
 
 
+@pytest.mark.parametrize("threaded", [False, True])
+def test_two_frames_in_flight_accumulate_the_same_buffer(pkg, oracle, tmp_path, threaded):
+    """--pipeline 2: a second context on a stream of another priority, frame k issued on lane k % 2 without waiting for frame k-1
+    (spt_progressive_frame_async), accumulations chained by events.  accumBuffer must be byte-identical to the serial loop's --
+    five frames, a camera request, four more: the clearing frame is rendered at the running sampleCount (:922-939) on whichever lane
+    is due -- and identical to the oracle's summed frames."""
+    w, h, samps = 64, 36, 1
+    sc, scene = _scene_file(pkg, tmp_path)
+    req = '{"action": "update_camera", "org": [0, -0.99, 0]}'
+    raws = {}
+    for pipe in (1, 2):
+        raw = tmp_path / f"accum{pipe}.bin"
+        args = [4 * samps, "--viewer", "--scene", scene, "--size", f"{w}x{h}", "--pipeline", pipe, "--dump-raw", raw, "--out", tmp_path / f"p{pipe}.ppm"]
+        if threaded:
+            err = _run(args + ["--threaded", "--frames", 6])
+            n = int(re.search(r"frames rendered (\d+)", err).group(1))
+            assert n >= 6
+            acc = np.zeros((h, w, 3), dtype=np.float32)
+            cam = pkg.pinhole_camera()
+            for frame in range(n):
+                acc = acc + oracle.render(sc, w, h, samps, seed=frame, normalise=False, camera=cam)[0]
+            assert np.array_equal(np.fromfile(raw, dtype=np.float32).reshape(h, w, 3), acc), pipe
+            continue
+        err = _run(args + ["--frames", 5, "--request", req, "--frames-after", 4])
+        m = re.search(r"frames rendered (\d+), sampleCount (\d+)", err)
+        assert int(m.group(1)) == 9 and int(m.group(2)) == 4
+        raws[pipe] = raw.read_bytes()
+    if not threaded:
+        assert raws[1] == raws[2]
+        cam2 = pkg.pinhole_camera(org=(0, -0.99, 0))
+        acc = oracle.render(sc, w, h, samps, seed=5, normalise=False, camera=cam2)[0]        # the clearing frame: seed = running sampleCount
+        for seed in (1, 2, 3):
+            acc = acc + oracle.render(sc, w, h, samps, seed=seed, normalise=False, camera=cam2)[0]
+        assert np.array_equal(np.frombuffer(raws[2], dtype=np.float32).reshape(h, w, 3), acc)
+
+
+def test_render_thread_failure_is_reported_not_fatal(pkg, tmp_path):
+    """An exception in the render thread (here: the kernel watchdog at 0.1 us makes every frame fail) must end the loop with its
+    message -- exit code 1 and "render thread: ..." on stderr -- not std::terminate (SIGABRT); a malformed request is refused on
+    the posting thread."""
+    sc, scene = _scene_file(pkg, tmp_path)
+    r = subprocess.run([CLI, "4", "--viewer", "--threaded", "--scene", str(scene), "--size", "640x360", "--frames", "2", "--watchdog", "1e-7",
+                        "--out", str(tmp_path / "x.ppm")], capture_output=True, timeout=300)
+    assert r.returncode == 1 and b"watchdog" in r.stderr, (r.returncode, r.stderr[-500:])
+    r = subprocess.run([CLI, "4", "--viewer", "--scene", str(scene), "--size", "32x18", "--frames", "1", "--request", '{"action": "update_camera", "org": [1, 2',
+                        "--out", str(tmp_path / "y.ppm")], capture_output=True, timeout=300)
+    assert r.returncode == 1 and r.stderr, (r.returncode, r.stderr[-500:])
+
+
 def test_render_thread_runs_concurrently(pkg, oracle, tmp_path):
     """Threaded mode (:895-901): the thread renders until stopped; whatever number of frames N it got to, accumBuffer is
     the sum of the oracle's frames 0..N-1 and the weight is 1/(N*spp)."""
