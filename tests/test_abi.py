@@ -30,6 +30,10 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.SYMBOLS) == declared          # the Python binding covers the whole header
     # test/tuning hooks live in an internal header, not in the drop-in boundary
     internal = _declared_symbols(INTERNAL_HEADER)
+    multi_hooks = [n for n in internal if n.startswith("spt_multi_")]       # hooks of libsmallpt_mi355x_multi.so
+    internal = [n for n in internal if n not in multi_hooks]
+    from optix_test_smallpt_amd._lib import MULTI_INTERNAL_SYMBOLS
+    assert sorted(MULTI_INTERNAL_SYMBOLS) == multi_hooks
     assert sorted(pkg.INTERNAL_SYMBOLS) == internal and not set(internal) & set(declared)
     for name in internal:
         assert hasattr(lib, name)
