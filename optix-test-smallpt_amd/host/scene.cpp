@@ -241,10 +241,17 @@ static void load_meshes(const JValue& root, Scene& sc)
             mi.mesh.positionBuffer = vec3_list(member(*e, "positions"), "positions");
             mi.mesh.normalBuffer = vec3_list(member(*e, "normals"), "normals");
             if (mi.mesh.normalBuffer.size() != mi.mesh.positionBuffer.size()) throw std::runtime_error("scene JSON: positions and normals differ in length");
-            for (const float3& t : vec3_list(member(*e, "indices"), "indices")) {
-                for (float f : {t.x, t.y, t.z}) {
-                    if (!(f >= 0 && f < (float)mi.mesh.positionBuffer.size()) || f != (float)(uint32_t)f) throw std::runtime_error("scene JSON: triangle index out of range");
-                    mi.mesh.indexBuffer.push_back((uint32_t)f);
+            // triangle indices are integers: read them in double (exact up to 2^53), not through the binary32 vec3 path, which
+            // would round an index above 2^24 to a neighbouring vertex
+            const JValue& idx = member(*e, "indices");
+            if (idx.kind != JValue::Array) throw std::runtime_error("scene JSON: \"indices\" must be an array of 3-number arrays");
+            const double nverts = (double)mi.mesh.positionBuffer.size();
+            for (auto& tri : idx.arr) {
+                if (tri->kind != JValue::Array || tri->arr.size() != 3) throw std::runtime_error("scene JSON: \"indices\" must be an array of 3-number arrays");
+                for (auto& c : tri->arr) {
+                    const double v = number(*c, "indices");
+                    if (!(v >= 0 && v < nverts) || v != std::floor(v)) throw std::runtime_error("scene JSON: triangle index out of range");
+                    mi.mesh.indexBuffer.push_back((uint32_t)v);
                 }
             }
         }

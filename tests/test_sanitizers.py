@@ -30,6 +30,11 @@ def test_host_json_reader_under_asan_ubsan(pkg, tmp_path):
              '{"spheres": [], "camera": {"origin": [1, 2]}}', '{"action": "update_camera", "org": [0, -0.99, 0]}',
              '{"action": "update_camera", "org": [0, "a", 0]}', '{"a": "\\u12', '{"a": "\\', "nul", "-", '{"spheres": [' * 2000,
              '{"spheres": [], "x": "' + "\\n" * 5000 + '"}']
+    mesh = ('{"meshes": [{"emission": [0,0,0], "color": [1,1,1], "refl": "DIFF", "positions": [[0,0,0],[1,0,0],[0,1,0]], '
+            '"normals": [[0,0,1],[0,0,1],[0,0,1]], "indices": [[0, 1, %s]]}]}')
+    # triangle indices are read as integers in double: 2.0000001 (which binary32 would round to 2), 3 (= vertex count) and
+    # 16777217 (2^24 + 1) are refused, 2 is accepted
+    texts += [mesh % "2", mesh % "2.0000001", mesh % "3", mesh % "16777217", mesh % "-1"]
     files = []
     for i, t in enumerate(texts):
         p = tmp_path / f"in{i}.json"
@@ -37,7 +42,7 @@ def test_host_json_reader_under_asan_ubsan(pkg, tmp_path):
         files.append(str(p))
     r = subprocess.run([str(exe), *files], capture_output=True, text=True, env=ENV)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert "scenes ok 2" in r.stdout          # the well-formed scene and the empty-spheres one
+    assert "scenes ok 3 rejected" in r.stdout          # the well-formed sphere scene, the empty-spheres one and the mesh with index 2
 
 
 def test_oracle_under_asan_ubsan(tmp_path):
