@@ -13,6 +13,8 @@ PASSES=(
  "FETCH_SIZE"
  "VALUBusy VALUUtilization"
  "MeanOccupancyPerCU OccupancyPercent"
+ "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH SQ_INSTS_SMEM"
+ "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_IFETCH"
 )
 i=0
 NP=${SPT_PMC_PASSES:-${#PASSES[@]}}

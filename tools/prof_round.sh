@@ -16,7 +16,7 @@ cp gpurun_out/configs.json gpurun_out/${TAG}_configs.json; cp gpurun_out/configs
 for X in config5 config3 mesh_256spp; do
   ( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${X}_stats -- python $R/bench.py --only-extra $X > $R/gpurun_out/${TAG}_${X}.json 2> $R/gpurun_out/${TAG}_${X}_stats.log )
   find $R/gpurun_out/${TAG}_${X}_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_${X}_kernel_stats.csv \;
-  SPT_PMC_ONLY="0 1 2 3 4" bash tools/prof_pmc_cmd.sh ${TAG}_${X}_pmc python bench.py --only-extra $X > gpurun_out/${TAG}_${X}_pmc.out 2>&1
+  SPT_PMC_ONLY="0 1 2 3 4 6 7" bash tools/prof_pmc_cmd.sh ${TAG}_${X}_pmc python bench.py --only-extra $X > gpurun_out/${TAG}_${X}_pmc.out 2>&1
   echo "== $X"; cat gpurun_out/${TAG}_${X}.json | cut -c1-400; head -4 gpurun_out/${TAG}_${X}_kernel_stats.csv | cut -c1-160
 done
 tail -3 gpurun_out/${TAG}_stats_bench.json; cat gpurun_out/${TAG}_bench_kernel_stats.csv | head -8; grep -A24 "poolkernel" gpurun_out/${TAG}_pmc_summary.txt | head -30; cat gpurun_out/${TAG}_configs.md
