@@ -72,6 +72,7 @@ struct spt_ctx {
     int accel = SPT_ACCEL_EXHAUSTIVE;
     bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
     float4* d_bvh_nodes = nullptr; float4* d_bvh_tris = nullptr; uint32_t* d_bvh_index = nullptr;
+    float4* d_thin_nodes = nullptr; float4* d_thin_tris = nullptr; uint32_t* d_thin_index = nullptr; uint32_t thin_count = 0;   // second hierarchy: thin triangles
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     uint32_t ntris = 0, ninst = 0;
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
@@ -195,6 +196,9 @@ void spt_destroy(spt_ctx* c)
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_tris) (void)hipFree(c->d_bvh_tris);
     if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
+    if (c->d_thin_nodes) (void)hipFree(c->d_thin_nodes);
+    if (c->d_thin_tris) (void)hipFree(c->d_thin_tris);
+    if (c->d_thin_index) (void)hipFree(c->d_thin_index);
     if (c->d_verts) (void)hipFree(c->d_verts);
     if (c->d_inst_first) (void)hipFree(c->d_inst_first);
     if (c->d_mesh_mats) (void)hipFree(c->d_mesh_mats);
@@ -547,6 +551,12 @@ static int build_accel(spt_ctx* c)
     SPT_HIP(c, upload(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4)));
     SPT_HIP(c, upload(c->d_bvh_tris, bvh.tris.data(), bvh.tris.size() * sizeof(float4)));
     SPT_HIP(c, upload(c->d_bvh_index, bvh.index.data(), bvh.index.size() * sizeof(uint32_t)));
+    c->thin_count = bvh.thin_count;
+    if (bvh.thin_count) {
+        SPT_HIP(c, upload(c->d_thin_nodes, bvh.thin_nodes.data(), bvh.thin_nodes.size() * sizeof(float4)));
+        SPT_HIP(c, upload(c->d_thin_tris, bvh.thin_tris.data(), bvh.thin_tris.size() * sizeof(float4)));
+        SPT_HIP(c, upload(c->d_thin_index, bvh.thin_index.data(), bvh.thin_index.size() * sizeof(uint32_t)));
+    }
     c->bvh_nodes = (uint32_t)(bvh.nodes.size() / 4); c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.leaves;
     c->bvh_ready = true;
     return 0;
@@ -589,7 +599,7 @@ int spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, cha
         spt::build_bvh(recs.data(), ntris, bvh);
         std::string reason;
         const bool ok = spt::validate_bvh(recs.data(), ntris, bvh, reason);
-        if (out4) { out4[0] = (uint32_t)(bvh.nodes.size() / 4); out4[1] = bvh.leaves; out4[2] = bvh.depth; out4[3] = ntris; }
+        if (out4) { out4[0] = (uint32_t)(bvh.nodes.size() / 4); out4[1] = bvh.leaves; out4[2] = bvh.depth; out4[3] = ntris - bvh.thin_count; }
         if (why && why_len) std::snprintf(why, why_len, "%s", reason.c_str());
         return ok ? 0 : 2;
     } catch (const std::exception& e) {
@@ -603,7 +613,10 @@ static spt::MParams mesh_params(const spt_ctx* c)
     spt::MParams M{};
     M.tris = c->d_tris; M.tri_index = c->d_tri_index; M.verts = c->d_verts; M.inst_first_tri = c->d_inst_first; M.mats = c->d_mesh_mats;
     M.ntris = c->ntris; M.ninst = c->ninst;
-    if (c->accel == SPT_ACCEL_BVH && c->bvh_ready) { M.bvh_nodes = c->d_bvh_nodes; M.bvh_tris = c->d_bvh_tris; M.bvh_index = c->d_bvh_index; }
+    if (c->accel == SPT_ACCEL_BVH && c->bvh_ready) {
+        M.bvh_nodes = c->d_bvh_nodes; M.bvh_tris = c->d_bvh_tris; M.bvh_index = c->d_bvh_index;
+        if (c->thin_count) { M.thin_nodes = c->d_thin_nodes; M.thin_tris = c->d_thin_tris; M.thin_index = c->d_thin_index; }
+    }
     return M;
 }
 

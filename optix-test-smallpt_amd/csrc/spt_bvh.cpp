@@ -196,17 +196,39 @@ struct Builder {
 
 }  // namespace
 
+// A needle: the record's normal cross(e1, e2) is tiny against the longest edge squared (zero-area triangles included)
+static bool thin_triangle(const float4* r)
+{
+    const double e1[3] = {r[1].x, r[1].y, r[1].z}, e2[3] = {r[2].x, r[2].y, r[2].z}, n[3] = {r[0].w, r[1].w, r[2].w};
+    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+    auto sq = [](const double* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; };
+    const double longest2 = std::max({sq(e1), sq(e2), sq(e3)});
+    return !(sq(n) > kBvhThinRatio * kBvhThinRatio * longest2 * longest2);
+}
+
 void build_bvh(const float4* recs, uint32_t ntris, Bvh& out)
 {
     out = Bvh{};
-    Builder b;
+    // two hierarchies of the same layout: the regular triangles (ray segment, distance cut) and the thin ones (whole line, no cut)
+    Bvh thin;
+    Builder b, t;
     b.recs = recs; b.rec_f4 = 3; b.out = &out;
-    b.box.resize(ntris); b.cen.resize(3 * (size_t)ntris);
+    t.recs = recs; t.rec_f4 = 3; t.out = &thin;
     for (uint32_t g = 0; g < ntris; ++g) {
-        b.box[g] = padded_box(recs + 3 * (size_t)g);
-        for (int a = 0; a < 3; ++a) b.cen[3 * (size_t)g + a] = 0.5f * b.box[g].mn[a] + 0.5f * b.box[g].mx[a];
+        const Box bx = padded_box(recs + 3 * (size_t)g);
+        Builder& dst = thin_triangle(recs + 3 * (size_t)g) ? t : b;
+        dst.ids.push_back(g);
+        dst.box.push_back(bx);
+        for (int a = 0; a < 3; ++a) dst.cen.push_back(0.5f * bx.mn[a] + 0.5f * bx.mx[a]);
     }
+    const uint32_t nthin = (uint32_t)t.ids.size();
     b.run();
+    if (nthin) {
+        t.run();
+        out.thin_nodes.swap(thin.nodes); out.thin_tris.swap(thin.tris); out.thin_index.swap(thin.index);
+        out.thin_count = nthin;
+        out.depth = std::max(out.depth, thin.depth);
+    }
 }
 
 // Box of a sphere, rounded outward, NOT padded: the traversal inflates node boxes per ray (spt_mesh.hip, closest_sphere_bvh)
@@ -307,8 +329,19 @@ static bool validate_walk(const float4* recs, uint32_t rec_f4, uint32_t ntris, c
 bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why)
 {
     std::vector<Box> pb(ntris);
-    for (uint32_t g = 0; g < ntris; ++g) pb[g] = padded_box(recs + 3 * (size_t)g);
-    return validate_walk(recs, 3, ntris, std::vector<uint32_t>(ntris, 1u), pb, bvh, why);
+    std::vector<uint32_t> regular(ntris, 1u), thin(ntris, 0u);
+    uint32_t nthin = 0;
+    for (uint32_t g = 0; g < ntris; ++g) {
+        pb[g] = padded_box(recs + 3 * (size_t)g);
+        if (thin_triangle(recs + 3 * (size_t)g)) { regular[g] = 0u; thin[g] = 1u; ++nthin; }
+    }
+    if (bvh.thin_count != nthin) { why = "thin-triangle count"; return false; }
+    if (!validate_walk(recs, 3, ntris, regular, pb, bvh, why)) return false;
+    if (nthin == 0) return bvh.thin_nodes.empty();
+    Bvh t;                                                       // the second hierarchy through the same structural walk
+    t.nodes = bvh.thin_nodes; t.tris = bvh.thin_tris; t.index = bvh.thin_index;
+    if (!validate_walk(recs, 3, ntris, thin, pb, t, why)) { why = "thin hierarchy: " + why; return false; }
+    return true;
 }
 
 bool validate_sphere_bvh(const float4* geom, const float* radius, uint32_t n, const Bvh& bvh, std::string& why)

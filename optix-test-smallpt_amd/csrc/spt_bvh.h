@@ -34,7 +34,16 @@ struct Bvh {
     std::vector<uint32_t> index;      // global (instance-major) triangle index of every leaf-order triangle
     std::vector<uint32_t> always;     // sphere hierarchies: global indices (ascending) of the spheres kept out of the tree
     uint32_t depth = 0, leaves = 0;
+    // Triangle hierarchies: THIN triangles (area <= 2^-10 of the longest edge squared: the needles makeSphereTriMesh puts at the poles,
+    // scene.cpp:13-27) live in a second hierarchy of the same layout that is traversed along the ray's whole LINE without a distance
+    // cut.  triIntersect divides by dot(rd, cross(e1, e2)) (scene.cpp:62), which is rounding noise for such a triangle whatever the ray:
+    // a ray passing within rounding distance of the needle gets a "hit" whose distance has nothing to do with where the needle is, so
+    // the exhaustive loop's answer can only be reproduced by testing the needle whenever the line meets its padded box.
+    std::vector<float4> thin_nodes, thin_tris;
+    std::vector<uint32_t> thin_index;
+    uint32_t thin_count = 0;
 };
+constexpr double kBvhThinRatio = 1.0 / 1024.0;   // |cross(e1, e2)| <= ratio * (longest edge)^2
 
 // recs: ntris x 3 records {v0, n.x} {v1 - v0, n.y} {v2 - v0, n.z}.  Throws std::runtime_error on non-finite vertices.
 void build_bvh(const float4* recs, uint32_t ntris, Bvh& out);

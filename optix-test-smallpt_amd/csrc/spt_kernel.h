@@ -53,6 +53,9 @@ struct MParams {
     const float4* bvh_nodes;       // 4 per node: both children's boxes + their references
     const float4* bvh_tris;        // the records of `tris` in leaf order
     const uint32_t* bvh_index;     // global triangle index of every leaf-order triangle
+    const float4* thin_nodes;      // second hierarchy over the thin triangles (spt_bvh.h), traversed along the whole line; null = none
+    const float4* thin_tris;
+    const uint32_t* thin_index;
     // sphere tables through the same kernel (spt_set_sphere_accel): bvh_tris holds one {centre, r*r} per sphere in leaf order,
     // `always` the spheres kept out of the tree; hits take centre / material from KParams::geom / mat
     const uint32_t* always;

@@ -183,9 +183,15 @@ def test_bvh_builder_structure(pkg):
              "shipped": [S((-1, 0, -4), 1.0), S((1.5, 0, -5), 1.0)], "mixed sizes": [S((0, -1e3 - 2, -6), 1e3, 24), S((0, 0, 0), 0.01, 8), tri],
              "soup": [_soup(pkg, 20000, 1)], "flat soup": [_soup(pkg, 5000, 2, flat=True)]}
     for name, meshes in cases.items():
-        rc, (nodes, leaves, depth, ntris), why = _selftest_bvh(pkg, meshes)
+        rc, (nodes, leaves, depth, ntris), why = _selftest_bvh(pkg, meshes)       # ntris = triangles of the main hierarchy (the thin ones have their own)
         assert rc == 0, (name, rc, why)
-        assert ntris == sum(m.triangle_count for m in meshes) and depth <= 32 and nodes >= 1, (name, nodes, leaves, depth, ntris)
+        total = sum(m.triangle_count for m in meshes)
+        assert ntris <= total and depth <= 32 and nodes >= 1, (name, nodes, leaves, depth, ntris)
+        # thin triangles: only makeSphereTriMesh's pole needles (two pole rows x 2L needles per sphere, scene.cpp:13-27; L = 32 / 24 / 8)
+        if "soup" in name:
+            assert total - ntris <= total // 200, (name, total - ntris)           # a random triangle is rarely that thin
+        else:
+            assert total - ntris == {"shipped": 2 * 2 * 64, "mixed sizes": 2 * 48 + 2 * 16}.get(name, 0), (name, total - ntris)
         if ntris > 4:
             assert leaves >= (ntris + 3) // 4 and nodes == leaves - 1, (name, nodes, leaves)
     rc, _, why = _selftest_bvh(pkg, [pkg.TriMesh(np.array([[0, 0, 0], [1, 0, 0], [np.inf, 1, 0]], dtype=np.float32), tri.normals, tri.indices)])
@@ -232,13 +238,15 @@ def _adversarial_rays(meshes, rs, n_random):
 def test_bvh_trace_rays_equals_exhaustive(pkg, renderer):
     """spt_trace_rays through the hierarchy returns, bit for bit, the Hit of the exhaustive loop (itself equal to the
     oracle's, test above) on random and adversarial rays over five kinds of scene -- except for rays lying in the plane of
-    the triangle they are reported to hit, where the reference's arithmetic returns noise (checked to be the only exception)."""
+    the REGULAR triangle they are reported to hit, where the reference's arithmetic returns noise (checked to be the only
+    exception).  Thin triangles (the pole needles of makeSphereTriMesh, zero-area triangles), for which that arithmetic is noise
+    for every ray, are tested along the ray's whole line by a second hierarchy and must agree on every ray."""
     S = pkg.make_sphere_trimesh
     rs = np.random.RandomState(11)
     scenes = {"shipped": [S((-1, 0, -4), 1.0), S((1.5, 0, -5), 1.0)], "cornell-like": _mesh_scene(pkg)[0],
               "soup": [_soup(pkg, 3000, 4)], "flat soup + ball": [_soup(pkg, 1500, 5, flat=True), S((0, 3, 0), 2.0, 8)],
               "one": [pkg.single_triangle_scene()[0][0]]}
-    total = in_plane = 0
+    total = in_plane = thin_far = 0
     try:
         for name, meshes in scenes.items():
             mats = [((0, 0, 0), (.5, .5, .5), pkg.DIFF)] * len(meshes)
@@ -261,7 +269,24 @@ def test_bvh_trace_rays_equals_exhaustive(pkg, renderer):
                 assert ref["dist"][i] < 1e20, (name, rays[i], got[i], ref[i])                 # a hit may only be lost, never invented
                 t = tri[first[ref["instId"][i]] + ref["triId"][i]]
                 e1, e2 = t[1] - t[0], t[2] - t[0]
-                det = abs(float(rays[i, 3:].astype(np.float64) @ np.cross(e1, e2)))           # what triIntersect divides by (scene.cpp:62)
+                nrm = np.cross(e1, e2)
+                longest2 = max(e1 @ e1, e2 @ e2, (e2 - e1) @ (e2 - e1))
+                o64, d64 = rays[i, :3].astype(np.float64), rays[i, 3:].astype(np.float64)
+                if np.linalg.norm(nrm) <= longest2 / 1024.0:
+                    # a THIN triangle's report may only be lost when the ray's line does not come near the needle at all: the
+                    # float normal of a needle is pure rounding noise, so a line that merely crosses the needle's supporting LINE
+                    # -- anywhere, here tens of units beyond its tip -- can pass the barycentric test (u = v = 0.5 exactly in
+                    # the case that showed this).  Every line that meets the needle's padded box must agree.
+                    pad = 0.25 * np.sqrt(longest2) + 1e-4 * np.abs(t).max()
+                    lo, hi = t.min(0) - pad, t.max(0) + pad
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        t0, t1 = (lo - o64) / d64, (hi - o64) / d64
+                    tn = np.where(d64 == 0, np.where((o64 >= lo) & (o64 <= hi), -np.inf, np.inf), np.minimum(t0, t1)).max()
+                    tf = np.where(d64 == 0, np.where((o64 >= lo) & (o64 <= hi), np.inf, -np.inf), np.maximum(t0, t1)).min()
+                    assert tn > tf, (name, "a thin triangle's report was lost although the line meets its box", rays[i], got[i], ref[i])
+                    thin_far += 1
+                    continue
+                det = abs(float(d64 @ nrm))                                                   # what triIntersect divides by (scene.cpp:62)
                 assert det < 1e-5 * np.linalg.norm(e1) * np.linalg.norm(e2), (name, det, rays[i], got[i], ref[i])
             assert len(bad) <= len(rays) // 500, (name, len(bad))
             assert (ref["dist"] < 1e20).sum() > len(rays) // 50, name
@@ -269,7 +294,8 @@ def test_bvh_trace_rays_equals_exhaustive(pkg, renderer):
     finally:
         renderer.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
     assert total > 400000
-    print(f"hierarchy == exhaustive on {total - in_plane} of {total} rays; {in_plane} in-plane rays differ")
+    print(f"hierarchy == exhaustive on {total - in_plane} of {total} rays; {in_plane - thin_far} rays in a regular triangle's plane and "
+          f"{thin_far} lines crossing a needle's supporting line away from the needle differ")
 
 
 @pytest.mark.gpu
