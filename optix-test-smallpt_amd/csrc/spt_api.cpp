@@ -312,6 +312,11 @@ static int build_sphere_grid_tables(spt_ctx* c)
     const uint32_t dsel = (c->variant >> 24) & 0xFFu;
     spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, grid_table_budget(c->n), g);
     if (!g.usable) { c->grid_why = g.why; return 0; }
+    // A cell that lists a third of the table means nearly everything shares a cell (the extent is set by a few large spheres that
+    // are not large enough for the always-tested list): the walk would test the whole table per lane with LDS gathers, slower than
+    // the exhaustive kernel's broadcast loop (measured 2.5x on such a table), which then keeps the scene.
+    const size_t in_grid = (size_t)c->n - g.always.size();
+    if (in_grid > 96 && (size_t)g.max_cell * 3 > in_grid) { c->grid_why = "a single cell lists more than a third of the spheres"; return 0; }
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
     auto upload = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
@@ -367,7 +372,7 @@ int spt_set_sphere_accel(spt_ctx* c, int accel)
     }
 }
 
-// Host-only self-test of the grid builder (no device call).  out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, 0}.
+// Host-only self-test of the grid builder (no device call).  out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, most references in one cell}.
 int spt_selftest_sphere_grid(const spt_sphere* s, uint32_t n, uint32_t cells_per_sphere, uint32_t* out8, char* why, uint32_t why_len)
 {
     try {
@@ -380,7 +385,7 @@ int spt_selftest_sphere_grid(const spt_sphere* s, uint32_t n, uint32_t cells_per
         const bool ok = g.usable && spt::validate_sphere_grid(geom.data(), radius.data(), n, g, reason);
         if (out8) {
             out8[0] = (uint32_t)g.P.dim[0]; out8[1] = (uint32_t)g.P.dim[1]; out8[2] = (uint32_t)g.P.dim[2]; out8[3] = g.P.nrefs;
-            out8[4] = (uint32_t)g.always.size(); out8[5] = (uint32_t)g.lds_bytes(); out8[6] = g.usable ? 1u : 0u; out8[7] = 0u;
+            out8[4] = (uint32_t)g.always.size(); out8[5] = (uint32_t)g.lds_bytes(); out8[6] = g.usable ? 1u : 0u; out8[7] = g.max_cell;
         }
         if (why && why_len) std::snprintf(why, why_len, "%s", reason.c_str());
         return ok ? 0 : 2;

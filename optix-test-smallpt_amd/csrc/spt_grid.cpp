@@ -133,6 +133,7 @@ void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, doub
             }
             const uint32_t cmax = count.empty() ? 0u : *std::max_element(count.begin(), count.end());
             fits = ncells * 4 + ((nrefs + 1) / 2) * 4 + huge.size() * 4 <= lds_budget && nrefs < (1u << (32 - kGridCountBits)) - 1u && cmax < (1u << kGridCountBits);
+            out.max_cell = cmax;
         }
         if (fits) {
             first.assign(ncells + 1, 0u);

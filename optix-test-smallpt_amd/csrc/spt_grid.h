@@ -42,7 +42,7 @@ namespace spt {
 constexpr uint32_t kGridBorder = 0xFFFFFFFFu;      // header of a border cell: the ray has left the table
 constexpr uint32_t kGridCountBits = 13;            // header = first reference << 13 | number of references (<= 8191)
 constexpr int32_t kGridMaxDim = 128;               // cells per axis
-constexpr uint32_t kGridAlways = 32;               // outsized spheres tested for every ray
+constexpr uint32_t kGridAlways = 1024;             // outsized spheres (more than 16 x the median radius) tested for every ray: at most this many
 
 // Everything the traversal needs besides the tables; plain data, passed by value to the kernel.
 struct GridParams {
@@ -141,6 +141,7 @@ struct SphereGrid {
     std::vector<uint16_t> refs;       // sphere indices, ascending inside a cell
     std::vector<uint32_t> always;     // ascending indices of the spheres tested for every ray
     double dmax = 0.0;                // Dmax of (1)
+    uint32_t max_cell = 0;            // most references in one cell
     std::vector<float> reach;         // R_j of (2) per sphere (0 for the always-tested ones); kept for validation
     bool usable = false;              // false: the scene does not fit (reason in why); the caller keeps another kernel
     std::string why;

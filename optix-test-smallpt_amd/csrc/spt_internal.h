@@ -61,7 +61,7 @@ int  spt_selftest_sphere_bvh(const spt_sphere* spheres, uint32_t n, uint32_t* ou
 /* Host-only self-test of the SPT_ACCEL_GRID builder (csrc/spt_grid.cpp): builds the uniform grid over the table at
  * `cells_per_sphere` (0 = the default resolution) and checks that every sphere is listed in every cell its error-bound cube
  * meets, that references are ascending and in range and that the ray test admits every origin inside the box.
- * out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, 0}; 0 = valid, 2 = not usable / invalid, 1 = builder error. */
+ * out8 = {dim x, dim y, dim z, references, always-tested spheres, table bytes, usable, most references in one cell}; 0 = valid, 2 = not usable / invalid, 1 = builder error. */
 int  spt_selftest_sphere_grid(const spt_sphere* spheres, uint32_t n, uint32_t cells_per_sphere, uint32_t* out8, char* why, uint32_t why_len);
 
 /* libsmallpt_mi355x_multi.so: kernel watchdog (spt_set_watchdog) of ONE rank's context, so that a test can make exactly one
