@@ -159,10 +159,9 @@ def extra_sphere_config(pkg, label, scene, samps, reps=3):
         d = r.diag()
         r.set_tuning(0, 0)
         rays = max(1, st4["bounces"])
-        always = 0
-        for x in scene:                                          # spheres more than 16 x the median radius are tested for every ray
-            always += 1 if abs(float(x["radius"])) > 16.0 * sorted(abs(float(y["radius"])) for y in scene)[n // 2] else 0
-        tests = d[1] / rays + min(always, 32)
+        radii = sorted(abs(float(x["radius"])) for x in scene)
+        always = sum(1 for v in radii if v > 16.0 * radii[n // 2])      # spheres more than 16 x the median radius are tested for every ray
+        tests = d[1] / rays + min(always, 1024)
         fl = 45.0 + bbar * (17.0 * tests + 100.0)
         ach = st["samples"] * fl / (k_ms * 1e-3) / 1e12
         res["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),

@@ -200,6 +200,38 @@ def test_pipelined_progressive_loop_mirrors_mesh_scenes_and_scene_changes(pkg, r
         renderer.set_scene(pkg.cornell9())
 
 
+def test_async_progressive_entry_contract(pkg, oracle):
+    """spt_progressive_attach / _frame_async / _wait through the C-ABI: misuse is refused with a message, two lanes accumulate
+    frames in call order into the owner's buffer (checked against the oracle's sum), the snapshot waits for both lanes."""
+    import ctypes as C
+    lib = pkg.load_library()
+    sc = pinhole_scene(pkg)
+    cam = pkg.pinhole_camera()
+    w, h, samps = 48, 27, 1
+    a, b = pkg.Renderer(0), pkg.Renderer(0)
+    try:
+        a.set_scene(sc); b.set_scene(sc)
+        err = lambda r: lib.spt_last_error(r._h).decode()
+        assert lib.spt_progressive_frame_async(a._h, a._h, C.byref(cam), samps, 0, 1) != 0 and "spt_progressive_begin" in err(a)
+        assert lib.spt_progressive_attach(b._h, a._h) != 0 and "spt_progressive_begin" in err(b)
+        assert lib.spt_progressive_begin(a._h, w, h) == 0
+        assert lib.spt_progressive_frame_async(b._h, a._h, C.byref(cam), samps, 0, 1) != 0 and "spt_progressive_attach" in err(b)
+        assert lib.spt_progressive_attach(b._h, a._h) == 0
+        assert lib.spt_progressive_frame_async(a._h, a._h, C.byref(cam), samps, 0, 1) == 0          # frame 0 clears
+        assert lib.spt_progressive_frame_async(a._h, a._h, C.byref(cam), samps, 9, 0) != 0 and "waited" in err(a)
+        assert lib.spt_progressive_frame_async(b._h, a._h, C.byref(cam), samps, 1, 0) == 0          # frame 1 on the other lane, in flight together
+        assert lib.spt_progressive_wait(a._h, None) == 0
+        assert lib.spt_progressive_frame_async(a._h, a._h, C.byref(cam), samps, 2, 0) == 0
+        out = np.empty((h, w, 3), dtype=np.float32)
+        assert lib.spt_progressive_snapshot(a._h, out.ctypes.data_as(C.c_void_p)) == 0            # waits for every accumulation issued
+        ref = sum(oracle.render(sc, w, h, samps, seed=k, normalise=False, camera=cam)[0] for k in range(3))
+        assert np.array_equal(out, ref)
+        assert lib.spt_progressive_wait(a._h, None) == 0 and lib.spt_progressive_wait(b._h, None) == 0
+        assert lib.spt_progressive_end(b._h) == 0 and lib.spt_progressive_end(a._h) == 0
+    finally:
+        a.close(); b.close()
+
+
 def test_monte_carlo_convergence(pkg, renderer):
     """Estimator sanity on the GPU path: images from independent seeds agree within Monte-Carlo noise, and the
     noise falls like 1/sqrt(spp) (a biased RNG stream or a broken roulette compensation would not)."""
