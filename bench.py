@@ -102,7 +102,7 @@ def interactive(pkg, r, dev, frames=600):
     cli = os.path.join(ROOT, "optix-test-smallpt_amd", "host", "smallpt_mi355x")
     if os.path.exists(cli):
         import subprocess
-        for lanes in (1, 2):
+        for lanes in (1, 2, 4, 8):
             try:
                 o = subprocess.run([cli, "4", "--viewer", "--size", f"{w}x{h}", "--org", "50,45,168", "--pipeline", str(lanes), "--bench-frames", str(frames)],
                                    capture_output=True, text=True, timeout=300)

@@ -81,6 +81,7 @@ struct spt_ctx {
     hipEvent_t ev_acc = nullptr;   // owner of an accumBuffer: completion of the most recent accumulation (any lane's stream)
     bool acc_recorded = false;
     bool frame_in_flight = false;  // a spt_progressive_frame_async of this lane has not been waited for
+    uint32_t lanes_attached = 0;   // owner: lanes attached so far (spreads them over the stream priorities)
     unsigned long long pool_stats[24] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
@@ -1012,6 +1013,7 @@ int spt_progressive_end(spt_ctx* c)
     c->prog_w = c->prog_h = 0;
     c->acc_recorded = false;
     c->frame_in_flight = false;
+    c->lanes_attached = 0;
     return 0;
 }
 
@@ -1039,11 +1041,17 @@ int spt_progressive_attach(spt_ctx* lane, spt_ctx* owner)
     if (lane->device != owner->device) return lane->fail("spt_progressive_attach: lane and owner are on different devices");
     if (int rc = spt_progressive_end(lane)) return rc;
     SPT_HIP(lane, hipSetDevice(lane->device));
-    // a stream of another priority than the owner's (created at the default priority by spt_create)
+    // a stream of another priority than the owner's (created at the default priority 0 by spt_create); further lanes take the
+    // remaining levels in turn (gfx950: -1, 0, 1), so that as few frames in flight as possible share a hardware queue
     int lo = 0, hi = 0;
     SPT_HIP(lane, hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = numerically largest = lowest priority
+    std::vector<int> levels;
+    for (int p = hi; p <= lo; ++p) if (p != 0) levels.push_back(p);
+    for (size_t a = 0, b = levels.size(); a + 1 < b; a += 2, --b) std::swap(levels[a + 1], levels[b - 1]);   // highest, lowest, second highest, ...
+    if (levels.empty()) levels.push_back(0);
+    const int prio = levels[owner->lanes_attached++ % levels.size()];
     if (lane->stream) { (void)hipStreamSynchronize(lane->stream); (void)hipStreamDestroy(lane->stream); lane->stream = nullptr; }
-    SPT_HIP(lane, hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, hi));
+    SPT_HIP(lane, hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio));
     SPT_HIP(lane, hipMalloc(reinterpret_cast<void**>(&lane->d_frame), (size_t)owner->prog_w * owner->prog_h * 3 * sizeof(float)));
     lane->prog_w = owner->prog_w; lane->prog_h = owner->prog_h;
     return 0;

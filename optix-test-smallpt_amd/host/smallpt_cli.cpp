@@ -63,7 +63,7 @@ int main(int argc, char* argv[])
             } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
         }
         else if (a == "--accel") { const std::string m = next(); if (m == "bvh") accel = SPT_ACCEL_BVH; else if (m == "exhaustive") accel = SPT_ACCEL_EXHAUSTIVE; else if (m == "grid") accel = SPT_ACCEL_GRID; else { std::fprintf(stderr, "--accel grid|bvh|exhaustive\n"); return 2; } }
-        else if (a == "--pipeline") { pipeline = std::atoi(next()); if (pipeline < 1 || pipeline > 4) { std::fprintf(stderr, "--pipeline 1..4\n"); return 2; } }
+        else if (a == "--pipeline") { pipeline = std::atoi(next()); if (pipeline < 1 || pipeline > 8) { std::fprintf(stderr, "--pipeline 1..8\n"); return 2; } }
         else if (a == "--bench-frames") bench_frames = std::atoi(next());
         else if (a == "--watchdog") watchdog = std::atof(next());
         else if (a == "--single-triangle") single_triangle = true;   // SingleTriangleScene of main(), smallpt.cpp:818-832

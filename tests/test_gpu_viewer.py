@@ -52,7 +52,7 @@ def test_render_thread_requests_and_snapshot(pkg, oracle, tmp_path):
 
 @pytest.mark.parametrize("threaded", [False, True])
 def test_two_frames_in_flight_accumulate_the_same_buffer(pkg, oracle, tmp_path, threaded):
-    """--pipeline 2: a second context on a stream of another priority, frame k issued on lane k % 2 without waiting for frame k-1
+    """--pipeline L (2 and 4 here): further contexts on streams of other priorities, frame k issued on lane k % L without waiting for frame k-1
     (spt_progressive_frame_async), accumulations chained by events.  accumBuffer must be byte-identical to the serial loop's --
     five frames, a camera request, four more: the clearing frame is rendered at the running sampleCount (:922-939) on whichever lane
     is due -- and identical to the oracle's summed frames."""
@@ -60,7 +60,7 @@ def test_two_frames_in_flight_accumulate_the_same_buffer(pkg, oracle, tmp_path, 
     sc, scene = _scene_file(pkg, tmp_path)
     req = '{"action": "update_camera", "org": [0, -0.99, 0]}'
     raws = {}
-    for pipe in (1, 2):
+    for pipe in (1, 2, 4):
         raw = tmp_path / f"accum{pipe}.bin"
         args = [4 * samps, "--viewer", "--scene", scene, "--size", f"{w}x{h}", "--pipeline", pipe, "--dump-raw", raw, "--out", tmp_path / f"p{pipe}.ppm"]
         if threaded:
@@ -78,7 +78,7 @@ def test_two_frames_in_flight_accumulate_the_same_buffer(pkg, oracle, tmp_path, 
         assert int(m.group(1)) == 9 and int(m.group(2)) == 4
         raws[pipe] = raw.read_bytes()
     if not threaded:
-        assert raws[1] == raws[2]
+        assert raws[1] == raws[2] == raws[4]
         cam2 = pkg.pinhole_camera(org=(0, -0.99, 0))
         acc = oracle.render(sc, w, h, samps, seed=5, normalise=False, camera=cam2)[0]        # the clearing frame: seed = running sampleCount
         for seed in (1, 2, 3):
