@@ -5,7 +5,7 @@
 //
 //   * ONE workgroup of 1024 threads per CU shares one LDS copy of the whole structure: sphere records {c, r*r} (16 B), cell headers
 //     (4 B: first reference << 13 | count, a one-cell border of sentinels), 16-bit sphere references, the always-tested list.
-//     Config 5 (1024 spheres): 16 + 55 + 11 KB of the CU's 160 KB; every lookup of the walk is an LDS read, none goes to memory.
+//     Config 5 (1024 spheres): 16 + 25 + 8 KB of the CU's 160 KB; every lookup of the walk is an LDS read, none goes to memory.
 //   * a lane owns a path (registers) and is in one of four states: NONE (needs a camera ray / a pending glass child / a task),
 //     FRESH (has a new ray), WALK (inside the grid), HIT (closest hit known, waits for shading).  The wave runs the phases
 //     regenerate -> begin walks -> walk -> shade in a loop; inside the walk phase a lane either TESTS the next sphere of its cell
@@ -27,13 +27,6 @@ constexpr int kGridBlock = 1024;
 constexpr uint32_t kGEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) + 1
 constexpr uint32_t kGInfKey = 0x60AD78ECu - kGEpsBias;           // key of 1e20f (maths.h:16)
 constexpr int kGChunk = 64;                                      // task ids fetched from the global queue per atomic
-
-#ifndef SPT_GRID_MULTISTEP
-#define SPT_GRID_MULTISTEP 0                                     // STEP body: keep stepping through empty cells while half of the steppers still do
-#endif
-#ifndef SPT_GRID_PREFETCH
-#define SPT_GRID_PREFETCH 0                                      // fetch the index of the next sphere reference one test ahead
-#endif
 
 enum : uint32_t { M_NONE = 0, M_FRESH = 1, M_WALK = 2, M_HIT = 3 };
 
@@ -81,7 +74,6 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
     int32_t wsx = 0, wsy = 0, wsz = 0;
     uint32_t wci = 0;
     uint32_t cur = 0, end = 0;                                   // references of the current cell still to test; end = 0 outside the walk
-    uint32_t nid = 0;                                            // sphere index of reference `cur` (fetched ahead)
     uint32_t near_key = kGInfKey, near_i = 0xFFFFFFFFu;
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;                      // wave-uniform: this wave's private range of task ids
@@ -237,7 +229,6 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                         wtx = w.tx; wty = w.ty; wtz = w.tz; wdx = w.dtx; wdy = w.dty; wdz = w.dtz; wsx = w.sx; wsy = w.sy; wsz = w.sz; wci = w.ci;
                         const uint32_t h = s_cells[wci];         // the start cell is clamped into the table: never a border cell
                         cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
-                        if (SPT_GRID_PREFETCH && cur < end) nid = s_refs[cur];
                         mode = M_WALK;
                     } else {
                         mode = M_HIT;
@@ -252,15 +243,14 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             uint32_t nwalk = (uint32_t)__popcll(__ballot(mode == M_WALK));
             uint32_t nidle = (uint32_t)__popcll(__ballot(mode == M_HIT));   // lanes whose hit waits for shading
             while (nwalk != 0u && nwalk * 16u >= nidle * leave_q) {      // leave_q = 0: every walk runs to its end
-                const bool wt = cur < end;                       // cur == end for lanes outside the walk
+                const bool wt = cur < end;                       // end = 0 for lanes outside the walk
                 const uint32_t nt = (uint32_t)__popcll(__ballot(wt));
                 if (2u * nt >= nwalk) {
-                    // ---- TEST: the next sphere of the lane's cell (its index was fetched when the previous one was tested) ----
+                    // ---- TEST: the next sphere of the lane's cell ----
                     if (STATS) { ++n_test_iters; n_tests += nt; }
                     if (wt) {
-                        const uint32_t i = SPT_GRID_PREFETCH ? nid : (uint32_t)s_refs[cur];
+                        const uint32_t i = s_refs[cur];
                         ++cur;
-                        if (SPT_GRID_PREFETCH && cur < end) nid = s_refs[cur];
                         const uint32_t key = sphere_key_g(s_geom[i], p.o, p.d);
                         // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
                         const bool better = (key < near_key) | ((key == near_key) & (i < near_i));
@@ -269,28 +259,20 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                     }
                     GSTAMP(2)
                 } else {
-                    // ---- STEP: leave the cell (all its spheres are tested); lanes that land in an empty cell go on while at least half
-                    // of the lanes that started stepping still do ----
-                    const uint32_t n0 = nwalk - nt;
-                    unsigned long long step_mask;
-                    do {
-                        const bool ws = mode == M_WALK && cur >= end;
-                        if (STATS) { ++n_step_iters; n_steps += (unsigned long long)__popcll(__ballot(ws)); }
-                        if (ws) {
-                            const float m = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));   // grid_walk_exit
-                            const float near_t = __uint_as_float(near_key + kGEpsBias);    // 1e20 while nothing is hit
-                            bool stop = !(m < near_t);           // spt_grid.h (3): every cell up to the hit has been visited
-                            if (!stop) {
-                                grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, m);
-                                const uint32_t h = s_cells[wci];
-                                stop = h == kGridBorder;         // left the table
-                                cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
-                            }
-                            if (stop) { mode = M_HIT; end = 0; }  // end = 0: "cur < end" is false outside the walk
-                            else if (SPT_GRID_PREFETCH && cur < end) nid = s_refs[cur];
+                    // ---- STEP: leave the cell (all its spheres are tested) ----
+                    if (STATS) { ++n_step_iters; n_steps += nwalk - nt; }
+                    if (mode == M_WALK && !wt) {
+                        const float m = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));   // grid_walk_exit
+                        const float near_t = __uint_as_float(near_key + kGEpsBias);    // 1e20 while nothing is hit
+                        bool stop = !(m < near_t);               // spt_grid.h (3): every cell up to the hit has been visited
+                        if (!stop) {
+                            grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, m);
+                            const uint32_t h = s_cells[wci];
+                            stop = h == kGridBorder;             // left the table
+                            cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
                         }
-                        step_mask = __ballot(mode == M_WALK && cur >= end);
-                    } while (SPT_GRID_MULTISTEP && 2u * (uint32_t)__popcll(step_mask) >= n0 && step_mask != 0ull);
+                        if (stop) { mode = M_HIT; end = 0; }      // end = 0: "cur < end" is false outside the walk
+                    }
                     const uint32_t still = (uint32_t)__popcll(__ballot(mode == M_WALK));
                     nidle += nwalk - still;
                     nwalk = still;
