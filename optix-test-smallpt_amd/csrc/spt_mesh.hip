@@ -90,6 +90,59 @@ __device__ __forceinline__ uint32_t closest_triangle(const float4* __restrict__ 
     return near_tri;
 }
 
+// The same exhaustive query for a FEW rays of the workgroup (at most kFewRays): instead of 256 lanes each walking all triangles
+// for their own ray -- a full pass of the tile loop even when one path of the workgroup is still alive, which is what the end of
+// a low-spp frame looks like -- the rays are listed in LDS and, ray by ray, the 256 threads share the triangles (thread t tests
+// triangles t, t + 256, ...), keep their best (key, global index) and the workgroup takes the minimum: smallest key, lowest index
+// among equal keys = what the reference's ascending loops with strict '<' select.  Same tri_test, so the same answer, in
+// ntris / 256 tests per thread and ray.  Up to 128 rays this beats the tile loop (measured: the shipped scene at 4 spp 13.4 -> 3.1 ms,
+// at 256 spp 136 -> 128 ms; with 256 it loses, 229 ms).  All threads of the workgroup call it together; nact = number of active lanes (> 0).
+constexpr int kFewRays = 128;
+__device__ __forceinline__ uint32_t closest_triangle_few(const float4* __restrict__ tris, uint32_t ntris, float4* s_tile, uint32_t nact,
+                                                         bool active, f3 ro, f3 rd, float& t_out)
+{
+    uint32_t* const s_u = reinterpret_cast<uint32_t*>(s_tile);   // [0] counter, [4 .. 4 + 8 kFewRays) rays, then per-wave partial minima, then results
+    float* const s_f = reinterpret_cast<float*>(s_tile);
+    unsigned long long* const s_part = reinterpret_cast<unsigned long long*>(s_u + 4 + 8 * kFewRays);   // kMeshBlock / 64 entries
+    unsigned long long* const s_res = s_part + kMeshBlock / 64;                                            // kFewRays entries
+    __syncthreads();                                             // the tile area is no longer read by a previous query
+    if (threadIdx.x == 0) s_u[0] = 0u;
+    __syncthreads();
+    uint32_t slot = 0;
+    if (active) {
+        slot = atomicAdd(&s_u[0], 1u);
+        float* r = s_f + 4 + 8 * slot;
+        r[0] = ro.x; r[1] = ro.y; r[2] = ro.z; r[3] = rd.x; r[4] = rd.y; r[5] = rd.z;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nact; ++k) {
+        const float* r = s_f + 4 + 8 * k;
+        const f3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+        uint32_t best_key = kMeshInfKey, best_tri = 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < ntris; i += kMeshBlock) {
+            float u, v;
+            const float t = tri_test(tris[3 * (size_t)i], tris[3 * (size_t)i + 1], tris[3 * (size_t)i + 2], o, d, u, v);
+            const uint32_t key = __float_as_uint(t) - 1u;
+            if (key < best_key) { best_key = key; best_tri = i; }     // ascending i per thread: strict '<' keeps the lowest index
+        }
+        unsigned long long m = ((unsigned long long)best_key << 32) | best_tri;   // lexicographic (key, index)
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long x = __shfl_down(m, off); m = x < m ? x : m; }
+        if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long a = s_part[0];
+            for (int w = 1; w < kMeshBlock / 64; ++w) a = s_part[w] < a ? s_part[w] : a;
+            s_res[k] = a;
+        }
+        __syncthreads();
+    }
+    uint32_t near_key = kMeshInfKey, near_tri = 0xFFFFFFFFu;
+    if (active) { const unsigned long long a = s_res[slot]; near_key = (uint32_t)(a >> 32); near_tri = (uint32_t)a; }
+    if (near_key >= kMeshInfKey) { near_key = kMeshInfKey; near_tri = 0xFFFFFFFFu; }
+    t_out = __uint_as_float(near_key + 1u);
+    return near_tri;
+}
+
 // The same query through the hierarchy (spt_bvh.h).  Per lane: a stack of <= 32 child references in LDS (entry e of thread
 // t at s_stack[e * blockDim + t]: conflict-free), near child first, both children's padded boxes tested against the ray
 // segment [0, current nearest] with widened slabs (a box is only skipped when the ray misses it by more than the widening;
@@ -324,10 +377,6 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
     const uint32_t lane = lane_id_m();
     const uint32_t gthread = blockIdx.x * kMeshBlock + threadIdx.x;
     float* const gstack = K.stack + (size_t)gthread * (3 * 12);                  // 3 pending children x 12 words per thread
-    const f3 cam_o = mk(K.cam_o[0], K.cam_o[1], K.cam_o[2]);
-    const f3 cam_d = mk(K.cam_d[0], K.cam_d[1], K.cam_d[2]);
-    const f3 cam_cx = mk(K.cam_cx[0], K.cam_cx[1], K.cam_cx[2]);
-    const f3 cam_cy = mk(K.cam_cy[0], K.cam_cy[1], K.cam_cy[2]);
 
     bool alive = false, task_valid = false, queue_empty = false;
     uint32_t task = 0, sp = 0, s_gen = 0, s_end = 0, px = 0, py = 0, cell = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
@@ -366,7 +415,16 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
             }
         }
         if (!alive && task_valid && s_gen < s_end) {
-            // camera ray of sample s_gen (smallpt.cpp:325-340 / :745-760), as in spt_kernel.hip phase C1
+            // camera ray of sample s_gen (smallpt.cpp:325-340 / :745-760), as in spt_kernel.hip phase C1.  The camera constants are read
+            // from the kernel-argument segment here (the empty asm keeps ~30 scalar loads from being hoisted out of the bounce loop,
+            // where they would push its scalars into spill lanes; K is the first kernel argument)
+            typedef const __attribute__((address_space(4))) KParams* KArgs;
+            KArgs kc = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kc));
+            const f3 cam_o = mk(kc->cam_o[0], kc->cam_o[1], kc->cam_o[2]);
+            const f3 cam_d = mk(kc->cam_d[0], kc->cam_d[1], kc->cam_d[2]);
+            const f3 cam_cx = mk(kc->cam_cx[0], kc->cam_cx[1], kc->cam_cx[2]);
+            const f3 cam_cy = mk(kc->cam_cy[0], kc->cam_cy[1], kc->cam_cy[2]);
             const uint32_t index_in_pixel = cell * K.samps + s_gen;              // :306
             k0 = mix32(p0 ^ (index_in_pixel * kGolden));
             k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
@@ -374,7 +432,7 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
             const float u2 = rng_draw(k0 + ((1u << 28) | 1u) * kGolden, k1);
             const uint32_t sx = cell & 1u, sy = cell >> 1;
             float ax, ay;
-            if (K.sampler == 0u) {
+            if (kc->sampler == 0u) {
                 const float r1 = 2 * u1;
                 const float q1 = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
                 const float dx = r1 < 1 ? q1 - 1 : 1 - q1;
@@ -383,20 +441,20 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
                 const float dy = r2 < 1 ? q2 - 1 : 1 - q2;
                 const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
                 const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
-                const double qx0 = tx * K.inv_w, qy0 = ty * K.inv_h;
-                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)K.w, tx), K.inv_w, qx0);
-                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)K.h, ty), K.inv_h, qy0);
+                const double qx0 = tx * kc->inv_w, qy0 = ty * kc->inv_h;
+                const double qx = __builtin_fma(__builtin_fma(-qx0, (double)kc->w, tx), kc->inv_w, qx0);
+                const double qy = __builtin_fma(__builtin_fma(-qy0, (double)kc->h, ty), kc->inv_h, qy0);
                 ax = (float)(qx - .5); ay = (float)(qy - .5);
             } else {
                 const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;
                 const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);
-                const float nx = (((float)px + 0.5f) + fx) * K.inv_wf;
-                const float ny = (((float)py + 0.5f) + fy) * K.inv_hf;
+                const float nx = (((float)px + 0.5f) + fx) * kc->inv_wf;
+                const float ny = (((float)py + 0.5f) + fy) * kc->inv_hf;
                 ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;
             }
             const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
             const float inv = rcp_exact(sqrt_exact(dot(dd, dd)));
-            p.o = cam_o + dd * K.cam_push;
+            p.o = cam_o + dd * kc->cam_push;
             p.d = dd * inv;
             p.w = mk(1, 1, 1); p.depth = 0; p.branch = 0; p.rbase = k0;
             ++s_gen;
@@ -404,13 +462,15 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
         }
         // exhaustive: the workgroup stages the triangle tiles together, so it leaves together; the traversals need no barrier and
         // a wave must not wait for the slowest ray of its three neighbours every bounce
-        if (GEOM == 0) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
+        uint32_t nalive = 0;                                     // exhaustive mode: paths alive in the whole workgroup
+        if (GEOM == 0) { nalive = (uint32_t)__syncthreads_count(alive ? 1 : 0); if (nalive == 0u) break; }
         else if (__ballot(alive) == 0ull) break;
 
         // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
         float t;
         const uint32_t tri = GEOM == 2 ? closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
                            : GEOM == 1 ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
+                           : nalive <= (uint32_t)kFewRays ? closest_triangle_few(M.tris, M.ntris, s_tile, nalive, alive, p.o, p.d, t)
                                        : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
         if (alive) {
             ++nbounce;
