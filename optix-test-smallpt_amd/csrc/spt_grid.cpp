@@ -76,17 +76,21 @@ void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, doub
         }
         const double diag0 = std::sqrt((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
         dmax = 1.3 * diag0;
-        for (int pass = 0; pass < 8; ++pass) {
+        auto cubes = [&](double d) {                      // union of the cubes c +- R(d); returns its diagonal
             for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
             for (uint32_t i : ids) {
-                const double R = reach_of(rs[i], dmax);
+                const double R = reach_of(rs[i], d);
                 const double c[3] = {geom[i].x, geom[i].y, geom[i].z};
                 for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a] - R); hi[a] = std::max(hi[a], c[a] + R); }
             }
-            const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            return std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        };
+        for (int pass = 0; pass < 8; ++pass) {
+            const double diag = cubes(dmax);
             if (diag <= 0.9 * dmax) break;                // origins anywhere in the box (and a little outside) pass the ray test
             dmax = 1.25 * diag;
         }
+        (void)cubes(dmax);                                // the box belongs to the Dmax that is used (also when the loop ran out)
         if (!std::isfinite(dmax) || !(dmax < 1e15)) { out.why = "extent overflows"; return; }
     }
     out.dmax = dmax;

@@ -69,3 +69,17 @@ def test_bvh_builder_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "bvh sanitizer run ok 44" in r.stdout
+
+
+def test_sphere_grid_builder_and_walk_under_asan_ubsan(tmp_path):
+    """The uniform grid of large sphere tables: host builder (csrc/spt_grid.cpp) and the traversal functions the kernel calls
+    (csrc/spt_grid.h) against the exhaustive loop, under ASan/UBSan (the -O2 run of the same harness is tests/test_sphere_accel.py)."""
+    if not _sanitizers_work(tmp_path):
+        pytest.skip("libasan/libubsan not usable in this environment")
+    exe = tmp_path / "grid_san"
+    subprocess.check_call(["g++", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", *SAN, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "sanitize", "grid_main.cpp"),
+                           os.path.join(ROOT, "optix-test-smallpt_amd", "csrc", "spt_grid.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "mismatches 0," in r.stdout and "grid harness ok" in r.stdout
