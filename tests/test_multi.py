@@ -141,3 +141,23 @@ def test_multi_mesh_scene_and_accel_pass_throughs(pkg, renderer):
             ref2, rst = renderer.render(40, 33, 1, seed=3, normalise=True)
             assert np.array_equal(img, ref2) and st["bounces"] == rst["bounces"], accel
     renderer.set_scene(pkg.cornell9())
+
+
+@pytest.mark.gpu
+def test_config4_full_size_eight_ranks_on_one_device(pkg, oracle):
+    """BASELINE config 4 at FULL size -- Cornell-9, 4096 x 4096, 4096 spp, eight ranks -- through the C++ multi-GPU front with the
+    eight ranks sharing this box's one device (copy transport; RCCL needs a device per rank, which the one-GPU box cannot give):
+    rows dealt out round-robin in blocks of 16, eight packed bands pulled to the root and scattered into the 201 MB framebuffer.
+    Rows at block and rank boundaries are compared with full oracle rows.  68.7 G samples: about 7 s of GPU time."""
+    w = h = 4096
+    samps = 1024
+    sc = pkg.cornell9()
+    with pkg.MultiRenderer((0,) * 8, copy_exchange=True) as m:
+        m.set_scene(sc)
+        img, st = m.render(w, h, samps, seed=0, normalise=True)
+    assert st["ndev"] == 8 and st["samples"] == w * h * 4 * samps
+    for row in (0, 15, 16, 127, 128, 2047, 4095):          # first / last row of a block, of a round of eight blocks, of the image
+        ref, _ = oracle.render(sc, w, h, samps, seed=0, normalise=True, row_begin=row, row_count=1)
+        assert np.array_equal(img[row:row + 1], ref), row
+    rate = st["samples"] / (st["total_ms"] * 1e-3) / 1e9
+    print(f"config 4 on one device, 8 ranks sharing it: {st['total_ms'] / 1e3:.2f} s, {rate:.2f} Gsamples/s, exchange {st['gather_ms']:.2f} ms")
