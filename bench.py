@@ -314,6 +314,7 @@ def main():
         # communicator set-up (RCCL channels over xGMI are created lazily on the first collective) stays outside
         # the timed region even with --warmup 0
         fa.gather()
+        fa.all_ok(True)              # ... and so does the all-reduce of the status agreement
     for _ in range(args.warmup):
         step()
     fence()
