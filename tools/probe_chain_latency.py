@@ -7,6 +7,8 @@ import optix_test_smallpt_amd as pkg
 
 r = pkg.Renderer(0)
 r.set_watchdog(20.0)
+if len(sys.argv) > 1:
+    r.set_tuning(0, int(sys.argv[1], 0))          # e.g. 0x400: the megakernel (one lane owns a path) instead of the pool kernel
 cam = pkg.pinhole_camera(vx=(1, 0, 0), vz=(0, 0, -1), org=(90, 0, 0), near=1.0)
 for label, refl in (("mirror", pkg.SPEC), ("glass", pkg.REFR), ("diffuse", pkg.DIFF)):
     sc = pkg.make_spheres([(100.0, (0, 0, 0), (0, 0, 0), (1, 1, 1), refl)] + [(1.0, (1e4 + 10 * i, 0, 0), (0, 0, 0), (.5, .5, .5), pkg.DIFF) for i in range(8)])
