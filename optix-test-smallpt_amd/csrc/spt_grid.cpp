@@ -169,6 +169,7 @@ void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, doub
     // ray test (1): farthest-corner distance against Dmax, with room for the binary32 evaluation of the test itself
     const double d2 = dmax * dmax * (1.0 - std::ldexp(1.0, -18));
     P.dfar2_max = round_down(d2);
+    P.tok_scale = round_down(0.99 * 1.5 * dmax * std::sqrt(std::ldexp(1.0, -19)));
     out.usable = true;
 }
 

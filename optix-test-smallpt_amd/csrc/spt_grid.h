@@ -9,10 +9,13 @@
 //
 //   (1) error of a reported hit.  With u = 2^-24, e = c - o, |d|^2 = 1 + eta, the point p = o + t d of a reported root t satisfies
 //       | |p - c|^2 - r^2 | <= 101 u (|e|^2 + r^2) + |eta| t^2   (intersectAnalytic divides by nothing).
-//       A ray takes the grid only if  D(o) := distance from o to the farthest corner of the grid box  <= Dmax  and
-//       | fl(d.d) - 1 | <= 2^-19 - 2^-22 (so |eta| <= 2^-19); every in-grid centre lies in the box, hence |e| <= Dmax and
-//       t <= |e| (1 + 3u) + r <= 1.5 Dmax.  With  E_j = 2^-17 (Dmax^2 + r_j^2) + 2^-19 (1.5 Dmax)^2  (128 u >= 101 u) the reported
-//       point lies within  sqrt(r_j^2 + E_j)  of c_j.
+//       A ray takes the grid only if  D(o) := distance from o to the farthest corner of the grid box  <= Dmax; every in-grid centre
+//       lies in the box, hence |e| <= Dmax and t <= 1.01 (|e| + r) <= 1.5 Dmax.  The walk of a ray is valid up to the parameter
+//       t_ok with |eta| t_ok^2 <= 2^-19 (1.5 Dmax)^2:  t_ok = inf when | fl(d.d) - 1 | <= 2^-19 - 2^-22 (so |eta| <= 2^-19: every
+//       fresh direction), else 0.99 * 1.5 Dmax * sqrt(2^-19 / (1.25 | fl(d.d) - 1 |)) (a mirror reflection is not renormalised,
+//       smallpt.cpp:218, so over a chain of bounces eta drifts; inside a closed mirror ball the hits are a few radii away and stay
+//       far below t_ok).  For every root t <= t_ok, with  E_j = 2^-17 (Dmax^2 + r_j^2) + 2^-19 (1.5 Dmax)^2  (128 u >= 101 u), the
+//       reported point lies within  sqrt(r_j^2 + E_j)  of c_j.
 //   (2) registration.  Sphere j is listed in every cell that meets the cube c_j +- R_j,  R_j = sqrt(r_j^2 + E_j) + dgrid,
 //       dgrid = 2^-12 Dmax; the grid box is the union of these cubes.
 //   (3) the walk.  tx/ty/tz = parameters at which the ray leaves the current cell, advanced by additions of cell / |d_a|
@@ -22,6 +25,9 @@
 //       visited once the computed exit time of the current cell is >= t_j.  The walk stops when that exit time reaches the current
 //       nearest t, or when it steps onto the one-cell border of sentinels around the table (no reported point lies outside the box,
 //       see (2)); the start cell is clamped into the table, which only adds cells.  Origins outside the box need no special case.
+//       Beyond t_ok nothing of this holds (a reported point may lie outside the box), so the walk's answer stands only if its
+//       nearest t is <= t_ok -- then every root below it is within the valid range and was covered; a walk that ends with a
+//       nearest t > t_ok (a miss included, also when it left the table) hands its ray to the exhaustive loop.
 //   (4) everything else -- rays that fail the test of (1), spheres more than 16 x the median radius (walls, lights: tested for
 //       every ray, like the hierarchy's always-list) -- goes through the exhaustive loop / is tested unconditionally.
 // Extra tests can never change the answer (every test is the reference's arithmetic on a sphere of the table), so the only
@@ -48,7 +54,8 @@ constexpr uint32_t kGridAlways = 1024;             // outsized spheres (more tha
 struct GridParams {
     float gmin[3], cell[3], inv_cell[3], gmax[3];  // the table covers [gmin, gmax], gmax = gmin + dim * cell
     float dfar2_max;                               // (1): squared farthest-corner distance a ray origin may have (already shrunk by 2^-20)
-    float eta_max;                                 // (1): bound on | fl(d.d) - 1 |
+    float eta_max;                                 // (1): | fl(d.d) - 1 | up to which a walk is valid at any parameter
+    float tok_scale;                               // (1): t_ok = tok_scale / sqrt(1.25 | fl(d.d) - 1 |) beyond that
     int32_t dim[3];                                // interior cells per axis
     int32_t stride_y, stride_z;                    // the table has a one-cell border: dim[0] + 2 and (dim[0] + 2) * (dim[1] + 2)
     uint32_t ncells, nrefs, nalways, n;            // table sizes; n = spheres in the scene
@@ -70,15 +77,22 @@ SPT_HD float grid_rcp(float x)
 #endif
 }
 
-// (1): may this ray use the grid?  NaN / inf in o or d fail every comparison and take the exhaustive loop.
-SPT_HD bool grid_ray_ok(const GridParams& G, float ox, float oy, float oz, float dx, float dy, float dz)
+// (1): may this ray use the grid, and up to which parameter is its walk valid?  NaN / inf in o or d fail the comparisons and
+// take the exhaustive loop.
+SPT_HD bool grid_ray_ok(const GridParams& G, float ox, float oy, float oz, float dx, float dy, float dz, float& t_ok)
 {
     const float ax = __builtin_fmaxf(__builtin_fabsf(ox - G.gmin[0]), __builtin_fabsf(ox - G.gmax[0]));
     const float ay = __builtin_fmaxf(__builtin_fabsf(oy - G.gmin[1]), __builtin_fabsf(oy - G.gmax[1]));
     const float az = __builtin_fmaxf(__builtin_fabsf(oz - G.gmin[2]), __builtin_fabsf(oz - G.gmax[2]));
     const float far2 = ax * ax + ay * ay + az * az;
     const float eta = __builtin_fabsf((dx * dx + dy * dy + dz * dz) - 1.0f);
-    return (far2 <= G.dfar2_max) & (eta <= G.eta_max);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float rs = __builtin_amdgcn_rsqf(1.25f * eta);       // 1 ulp; the 0.99 in tok_scale has room for it
+#else
+    const float rs = 1.0f / __builtin_sqrtf(1.25f * eta);
+#endif
+    t_ok = eta <= G.eta_max ? __builtin_inff() : G.tok_scale * rs;
+    return (far2 <= G.dfar2_max) & (eta < 0.25f);               // (eta < 1/4: a direction that is no direction at all; also refuses NaN)
 }
 
 // One axis of the start of a walk: cell index (clamped into the table), exit parameter, parameter per cell, index step.

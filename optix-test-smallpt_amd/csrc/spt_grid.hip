@@ -75,6 +75,8 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
     uint32_t wci = 0;
     uint32_t cur = 0, end = 0;                                   // references of the current cell still to test; end = 0 outside the walk
     uint32_t near_key = kGInfKey, near_i = 0xFFFFFFFFu;
+    float t_ok = 0.f;                                            // the lane's walk is valid up to this ray parameter (spt_grid.h (1))
+    bool redo = false;                                           // the walk had to give up: phase B runs the exhaustive loop for this ray
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;                      // wave-uniform: this wave's private range of task ids
     // statistics (wave-uniform counters, lane 0 reports)
@@ -199,9 +201,11 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             if (__ballot(fresh) != 0ull) {
                 bool ok = false;
                 if (fresh) {
-                    ++nbounce;
+                    if (!redo) ++nbounce;                        // (a ray handed back by its walk was counted when it started)
                     near_key = kGInfKey; near_i = 0u;            // index 0 with the inf key: never replaced by another inf key, never taken for a hit
-                    ok = grid_ray_ok(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z);
+                    ok = grid_ray_ok(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, t_ok) && !redo;
+                    if (!ok) t_ok = __builtin_inff();            // the exhaustive loop's answer needs no range
+                    redo = false;
                 }
                 for (uint32_t k = 0; k < G.nalways; ++k) {       // the walls and the light of a Cornell box: ascending indices, strict '<' (smallpt.cpp:61)
                     const uint32_t i = s_refs[G.nrefs + k];
@@ -282,6 +286,9 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
         }
 
         // ================= D: shadePaths for the lanes whose closest hit is known (smallpt.cpp:168-263 under D2-D6, D18, D19) =================
+        // A walk's answer (hit or miss) stands only inside the ray's valid range (spt_grid.h (1): a direction whose length has drifted
+        // over a chain of mirror bounces is valid up to t_ok only); otherwise the exhaustive loop takes the ray over in the next round.
+        if (mode == M_HIT && __uint_as_float(near_key + kGEpsBias) > t_ok) { mode = M_FRESH; redo = true; }
         if (mode == M_HIT) {
             if (STATS) ++n_shade_lanes;
             mode = M_NONE;
