@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
     uint32_t cur = 0, end = 0;                                   // references of the current cell still to test; end = 0 outside the walk
     uint32_t near_key = kGInfKey, near_i = 0xFFFFFFFFu;
     float t_ok = 0.f;                                            // the lane's walk is valid up to this ray parameter (spt_grid.h (1))
-    bool redo = false;                                           // the walk had to give up: phase B runs the exhaustive loop for this ray
+    bool redo = false;                                           // the walk ended beyond it: phase B runs the exhaustive loop for this ray
     uint32_t nbounce = 0, nkill = 0;
     uint32_t chunk_next = 0, chunk_end = 0;                      // wave-uniform: this wave's private range of task ids
     // statistics (wave-uniform counters, lane 0 reports)
@@ -199,11 +199,17 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
         {
             const bool fresh = mode == M_FRESH;
             if (__ballot(fresh) != 0ull) {
+                // the ~25 grid constants are read from the kernel-argument segment here (G is the argument after K), like the camera
+                // constants of phase A: kept in scalar registers across the whole loop they push the walk's scalars into spill lanes
+                typedef const __attribute__((address_space(4))) GridParams* GArgs;
+                GArgs gp = (GArgs)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KParams));
+                asm volatile("" : "+s"(gp));
+                const GridParams& GB = *(const GridParams*)gp;
                 bool ok = false;
                 if (fresh) {
                     if (!redo) ++nbounce;                        // (a ray handed back by its walk was counted when it started)
                     near_key = kGInfKey; near_i = 0u;            // index 0 with the inf key: never replaced by another inf key, never taken for a hit
-                    ok = grid_ray_ok(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, t_ok) && !redo;
+                    ok = grid_ray_ok(GB, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, t_ok) && !redo;
                     if (!ok) t_ok = __builtin_inff();            // the exhaustive loop's answer needs no range
                     redo = false;
                 }
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 if (fresh) {
                     if (ok) {
                         GridWalk w;
-                        grid_walk_begin(G, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, w);
+                        grid_walk_begin(GB, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, w);
                         wtx = w.tx; wty = w.ty; wtz = w.tz; wdx = w.dtx; wdy = w.dty; wdz = w.dtz; wsx = w.sx; wsy = w.sy; wsz = w.sz; wci = w.ci;
                         const uint32_t h = s_cells[wci];         // the start cell is clamped into the table: never a border cell
                         cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
