@@ -27,6 +27,20 @@ inline void cell_range(double lo, double hi, double gmin, double cell, int32_t d
     i1 = (int32_t)std::min(std::max(b, 0.0), (double)(dim - 1));
 }
 
+// does the ball of radius R around c meet cell (x, y, z) of the table?  (2) of spt_grid.h: squared distance from c to the cell's box in
+// double, with a relative reserve far above the double rounding of the box edges
+inline bool ball_meets_cell(const double c[3], double R, const GridParams& P, int32_t x, int32_t y, int32_t z)
+{
+    const int32_t idx[3] = {x, y, z};
+    double d2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = (double)P.gmin[a] + (double)idx[a] * (double)P.cell[a], hi = lo + (double)P.cell[a];
+        const double d = std::max(0.0, std::max(lo - c[a], c[a] - hi));
+        d2 += d * d;
+    }
+    return d2 <= R * R * (1.0 + 1e-9);
+}
+
 }  // namespace
 
 void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, double cells_per_sphere, size_t lds_budget, SphereGrid& out)
@@ -129,11 +143,11 @@ void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, doub
                 const double c[3] = {geom[i].x, geom[i].y, geom[i].z};
                 int32_t r0[3], r1[3];
                 for (int a = 0; a < 3; ++a) cell_range(c[a] - out.reach[i], c[a] + out.reach[i], P.gmin[a], P.cell[a], dim[a], r0[a], r1[a]);
-                nrefs += (size_t)(r1[0] - r0[0] + 1) * (r1[1] - r0[1] + 1) * (r1[2] - r0[2] + 1);
-                if (nrefs * 2 > lds_budget) break;
                 for (int32_t z = r0[2]; z <= r1[2]; ++z)
                     for (int32_t y = r0[1]; y <= r1[1]; ++y)
-                        for (int32_t x = r0[0]; x <= r1[0]; ++x) ++count[(size_t)(x + 1) + (size_t)P.stride_y * (y + 1) + (size_t)P.stride_z * (z + 1)];
+                        for (int32_t x = r0[0]; x <= r1[0]; ++x)
+                            if (ball_meets_cell(c, out.reach[i], P, x, y, z)) { ++count[(size_t)(x + 1) + (size_t)P.stride_y * (y + 1) + (size_t)P.stride_z * (z + 1)]; ++nrefs; }
+                if (nrefs * 2 > lds_budget) break;
             }
             const uint32_t cmax = count.empty() ? 0u : *std::max_element(count.begin(), count.end());
             fits = ncells * 4 + ((nrefs + 1) / 2) * 4 + huge.size() * 4 <= lds_budget && nrefs < (1u << (32 - kGridCountBits)) - 1u && cmax < (1u << kGridCountBits);
@@ -151,7 +165,8 @@ void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, doub
                 for (int32_t z = r0[2]; z <= r1[2]; ++z)
                     for (int32_t y = r0[1]; y <= r1[1]; ++y)
                         for (int32_t x = r0[0]; x <= r1[0]; ++x)
-                            out.refs[fill[(size_t)(x + 1) + (size_t)P.stride_y * (y + 1) + (size_t)P.stride_z * (z + 1)]++] = (uint16_t)i;
+                            if (ball_meets_cell(c, out.reach[i], P, x, y, z))
+                                out.refs[fill[(size_t)(x + 1) + (size_t)P.stride_y * (y + 1) + (size_t)P.stride_z * (z + 1)]++] = (uint16_t)i;
             }
             out.cells.assign(ncells, kGridBorder);
             for (int32_t z = 0; z < dim[2]; ++z)
@@ -214,9 +229,10 @@ bool validate_sphere_grid(const float4* geom, const float* radius, uint32_t n, c
         for (int32_t z = r0[2]; z <= r1[2]; ++z)
             for (int32_t y = r0[1]; y <= r1[1]; ++y)
                 for (int32_t x = r0[0]; x <= r1[0]; ++x) {
+                    if (!ball_meets_cell(c, need, P, x, y, z)) continue;
                     const uint32_t h = g.cells[(size_t)(x + 1) + (size_t)P.stride_y * (y + 1) + (size_t)P.stride_z * (z + 1)];
                     const uint32_t f = h >> kGridCountBits, cn = h & ((1u << kGridCountBits) - 1u);
-                    if (!std::binary_search(g.refs.begin() + f, g.refs.begin() + f + cn, (uint16_t)i)) { why = "sphere " + std::to_string(i) + " missing from a cell of its cube"; return false; }
+                    if (!std::binary_search(g.refs.begin() + f, g.refs.begin() + f + cn, (uint16_t)i)) { why = "sphere " + std::to_string(i) + " missing from a cell of its ball"; return false; }
                 }
     }
     // the ray test must admit every origin inside the box

@@ -16,12 +16,12 @@
 //       smallpt.cpp:218, so over a chain of bounces eta drifts; inside a closed mirror ball the hits are a few radii away and stay
 //       far below t_ok).  For every root t <= t_ok, with  E_j = 2^-17 (Dmax^2 + r_j^2) + 2^-19 (1.5 Dmax)^2  (128 u >= 101 u), the
 //       reported point lies within  sqrt(r_j^2 + E_j)  of c_j.
-//   (2) registration.  Sphere j is listed in every cell that meets the cube c_j +- R_j,  R_j = sqrt(r_j^2 + E_j) + dgrid,
-//       dgrid = 2^-12 Dmax; the grid box is the union of these cubes.
+//   (2) registration.  Sphere j is listed in every cell whose box is within R_j of c_j (Euclidean),  R_j = sqrt(r_j^2 + E_j) + dgrid,
+//       dgrid = 2^-12 Dmax; the grid box is the union of the cubes c_j +- R_j.
 //   (3) the walk.  tx/ty/tz = parameters at which the ray leaves the current cell, advanced by additions of cell / |d_a|
 //       (<= 3 * 128 steps; accumulated error <= 4 (steps + 4) u t, i.e. a position error below 2^-13 Dmax < dgrid).  For every true
 //       parameter t the walk is, at its computed time t, in a cell whose slab contains the true point up to that error in every
-//       axis -- so the cell in which a reported point p_j lies (or a neighbour within dgrid, where j is listed as well) has been
+//       axis (sqrt(3) 2^-13 Dmax < dgrid as a distance) -- so a cell within dgrid of the reported point p_j, in which j is listed, has been
 //       visited once the computed exit time of the current cell is >= t_j.  The walk stops when that exit time reaches the current
 //       nearest t, or when it steps onto the one-cell border of sentinels around the table (no reported point lies outside the box,
 //       see (2)); the start cell is clamped into the table, which only adds cells.  Origins outside the box need no special case.
