@@ -92,7 +92,8 @@ typedef struct spt_stats {
 
 #define SPT_FLAG_NORMALISE 1u  /* divide by spp (cpuRender); otherwise return the raw sum (render()) */
 #define SPT_MAX_DEPTH      4096u
-#define SPT_MAX_SPHERES    4096u  /* LDS-staged: 16 B geometry per sphere */
+#define SPT_MAX_SPHERES    4096u  /* the exhaustive kernels stage the table in LDS: 16 B geometry per sphere */
+#define SPT_MAX_SPHERES_ACCEL 1048576u  /* through a structure (spt_set_sphere_accel: the grid up to about 9 000 spheres, the hierarchy beyond) */
 
 /* Creates a context on HIP device `device_id` (its own non-blocking stream, events, scratch). */
 int  spt_create(int device_id, spt_ctx** out);
@@ -101,7 +102,10 @@ const char* spt_last_error(const spt_ctx* ctx);  /* ctx may be NULL: last error 
 int  spt_api_version(void);
 int  spt_device_count(void);
 
-/* Uploads the sphere table (replaces the global spheres[] + materials vector, smallpt.cpp:31-50,288-290). */
+/* Uploads the sphere table (replaces the global spheres[] + materials vector, smallpt.cpp:31-50,288-290).  Up to SPT_MAX_SPHERES
+ * in every mode; up to SPT_MAX_SPHERES_ACCEL in the default mode and SPT_ACCEL_BVH (spt_set_sphere_accel), where the table sits
+ * behind a structure, provided every radius is >= 2^-30 and every coordinate within 1e15 (else the call fails and the previous
+ * scene stays current). */
 int  spt_set_scene(spt_ctx* ctx, const spt_sphere* spheres, uint32_t n);
 
 /* ---- triangle meshes: the reference's Intersector seam (smallpt.cpp:427-473 CPUIntersector, :475-603 OptixIntersector) ----
@@ -153,7 +157,8 @@ int  spt_set_mesh_accel(spt_ctx* ctx, int accel);
  * more than that bound (csrc/spt_grid.h).
  *   SPT_ACCEL_GRID (default): a uniform grid held in LDS; spheres more than 16 x the median radius (walls, lights) are tested
  *     for every ray, rays outside the error bound's precondition take the exhaustive loop.  Scenes that do not qualify (<= 24
- *     spheres, degenerate radii / coordinates, tables beyond the LDS) run the exhaustive kernels as before.
+ *     spheres, degenerate radii / coordinates, tables beyond the LDS: about 9 000 spheres) go through the hierarchy below from
+ *     1024 spheres on and through the exhaustive kernels otherwise.
  *   SPT_ACCEL_BVH: a bounding-volume hierarchy with per-ray inflated boxes (round 2).
  *   SPT_ACCEL_EXHAUSTIVE: every sphere for every ray. */
 #define SPT_ACCEL_GRID       2

@@ -225,6 +225,7 @@ int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
 //   r*r (scene.cpp:133), pmax = fmaxf(color) (smallpt.cpp:177), color*(1/pmax) (smallpt.cpp:192).
 static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n);
 static int build_sphere_accel(spt_ctx* c);
+static int build_default_sphere_structure(spt_ctx* c);
 static int build_sphere_grid_tables(spt_ctx* c);
 
 int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
@@ -239,10 +240,27 @@ int spt_set_scene(spt_ctx* c, const spt_sphere* s, uint32_t n)
 
 static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
 {
-    if (n > SPT_MAX_SPHERES) return c->fail("spt_set_scene: %u spheres > SPT_MAX_SPHERES (%u)", n, SPT_MAX_SPHERES);
+    if (n > SPT_MAX_SPHERES_ACCEL) return c->fail("spt_set_scene: %u spheres > SPT_MAX_SPHERES_ACCEL (%u)", n, SPT_MAX_SPHERES_ACCEL);
     if (n && !s) return c->fail("spt_set_scene: spheres is NULL");
     for (uint32_t i = 0; i < n; ++i)
         if (s[i].refl < SPT_DIFF || s[i].refl > SPT_REFR) return c->fail("spt_set_scene: sphere %u has refl=%d", i, s[i].refl);
+    // The un-guarded square root (sqrt_rsq) in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
+    // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
+    bool needs_guard = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float big = std::fmax(std::fmax(std::fabs(s[i].center[0]), std::fabs(s[i].center[1])),
+                                    std::fmax(std::fabs(s[i].center[2]), std::fabs(s[i].radius)));
+        if (!(s[i].radius * s[i].radius >= 0x1p-60f) || !(big <= 1e15f)) needs_guard = true;
+    }
+    // The exhaustive kernels stage the whole table in LDS (SPT_MAX_SPHERES); a larger table exists only behind a structure -- the
+    // grid while its tables fit one CU's LDS, the hierarchy (records in global memory) beyond -- whose error bounds exclude the
+    // degenerate scenes of the guarded build.
+    if (n > SPT_MAX_SPHERES) {
+        if (c->sphere_accel == SPT_ACCEL_EXHAUSTIVE)
+            return c->fail("spt_set_scene: %u spheres > SPT_MAX_SPHERES (%u): the exhaustive kernels stage the table in LDS; larger tables need SPT_ACCEL_GRID or SPT_ACCEL_BVH", n, SPT_MAX_SPHERES);
+        if (needs_guard)
+            return c->fail("spt_set_scene: %u spheres > SPT_MAX_SPHERES (%u) with radii below 2^-30 or coordinates beyond 1e15, which only the exhaustive kernels take", n, SPT_MAX_SPHERES);
+    }
     SPT_HIP(c, hipSetDevice(c->device));
     if (c->pending) SPT_HIP(c, hipEventSynchronize(c->ev_stop));
     const uint32_t cap = n ? n : 1;
@@ -280,14 +298,7 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     for (uint32_t i = 0; i < n; ++i) c->h_radius[i] = s[i].radius;
     c->sbvh_ready = false;
     c->grid_ready = false;
-    // The un-guarded square root (sqrt_rsq) in the closest-hit loop is exact for det = 0 or 2^-96 <= det < inf.  That holds
-    // whenever r*r >= 2^-60 and no coordinate can overflow b*b / dot(op,op); other scenes get the guarded build.
-    c->needs_guard = false;
-    for (uint32_t i = 0; i < n; ++i) {
-        const float big = std::fmax(std::fmax(std::fabs(s[i].center[0]), std::fabs(s[i].center[1])),
-                                    std::fmax(std::fabs(s[i].center[2]), std::fabs(s[i].radius)));
-        if (!(s[i].radius * s[i].radius >= 0x1p-60f) || !(big <= 1e15f)) c->needs_guard = true;
-    }
+    c->needs_guard = needs_guard;
     // Pool kernel: unrolled closest hit (<= 24 spheres), un-guarded sqrt, and path weights that only the glass factors
     // can push out of the finite range (colours in [0,1], finite emission) -- it tracks that case with a flag.
     c->pool_ok = n <= (uint32_t)spt_pool_max_spheres() && !c->needs_guard;
@@ -295,7 +306,7 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
         for (int k = 0; k < 3; ++k)
             if (!(s[i].color[k] >= 0.f && s[i].color[k] <= 1.f) || !(std::fabs(s[i].emission[k]) <= 3e38f)) c->pool_ok = false;
     if (c->sphere_accel == SPT_ACCEL_BVH) return build_sphere_accel(c);
-    return c->sphere_accel == SPT_ACCEL_GRID ? build_sphere_grid_tables(c) : 0;
+    return c->sphere_accel == SPT_ACCEL_GRID ? build_default_sphere_structure(c) : 0;   // (n > SPT_MAX_SPHERES: always one of the two)
 }
 
 // LDS the grid kernel may spend on cell headers + references + the always-list, beside the 16-byte sphere records (one workgroup per CU)
@@ -336,6 +347,17 @@ static int build_sphere_grid_tables(spt_ctx* c)
     return 0;
 }
 
+// SPT_ACCEL_GRID on a table the grid does not take (beyond the LDS, everything in one cell; not: degenerate radii / coordinates): from
+// kSphereBvhFrom spheres on the hierarchy -- exhaustive-equivalent as well -- takes the scene instead of the exhaustive kernel
+// (measured exhaustive / hierarchy: 1024 spheres 375 / 483, 4096 spheres 62 / 315 Msamples/s; below ~1000 the exhaustive kernel wins).
+constexpr uint32_t kSphereBvhFrom = 1024;
+static int build_default_sphere_structure(spt_ctx* c)
+{
+    const int rc = build_sphere_grid_tables(c);
+    if (rc != 0 || c->grid_ready || c->n < kSphereBvhFrom || c->needs_guard) return rc;
+    return c->sbvh_ready ? 0 : build_sphere_accel(c);
+}
+
 // Hierarchy over the current sphere table (spt_bvh.h build_sphere_bvh); the caller holds the C-boundary try block.
 static int build_sphere_accel(spt_ctx* c)
 {
@@ -363,11 +385,13 @@ int spt_set_sphere_accel(spt_ctx* c, int accel)
 {
     if (!c) return 1;
     if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH && accel != SPT_ACCEL_GRID) return c->fail("spt_set_sphere_accel: unknown mode %d", accel);
+    if (accel == SPT_ACCEL_EXHAUSTIVE && !c->mesh_scene && c->d_geom && c->n > SPT_MAX_SPHERES)
+        return c->fail("spt_set_sphere_accel: the current table has %u spheres > SPT_MAX_SPHERES (%u), which the exhaustive kernels cannot stage in LDS", c->n, SPT_MAX_SPHERES);
     c->sphere_accel = accel;
     if (accel == SPT_ACCEL_EXHAUSTIVE || c->mesh_scene || !c->d_geom) return 0;
     try {
         if (accel == SPT_ACCEL_BVH) return c->sbvh_ready ? 0 : build_sphere_accel(c);
-        return c->grid_ready ? 0 : build_sphere_grid_tables(c);
+        return c->grid_ready ? 0 : build_default_sphere_structure(c);
     } catch (const std::exception& e) {
         return c->fail("spt_set_sphere_accel: %s", e.what());
     }
@@ -812,7 +836,10 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
     }
 
     // ---- triangle-mesh scene (spt_mesh.hip), or a sphere table too large for the pool kernel through its hierarchy ----
-    const bool sphere_bvh = !c->mesh_scene && c->sphere_accel == SPT_ACCEL_BVH && c->sbvh_ready && c->n > (uint32_t)spt_pool_max_spheres();
+    const bool sphere_bvh = !c->mesh_scene && c->sbvh_ready && c->n > (uint32_t)spt_pool_max_spheres() &&
+                            (c->sphere_accel == SPT_ACCEL_BVH || (c->sphere_accel == SPT_ACCEL_GRID && !c->grid_ready && c->n >= kSphereBvhFrom && !c->needs_guard));
+    if (!c->mesh_scene && !sphere_bvh && c->n > SPT_MAX_SPHERES)    // (a grid table whose launch conditions this call does not meet)
+        return c->fail("spt_render_rows_device: %u spheres > SPT_MAX_SPHERES (%u) render through the grid only with camera coordinates within 1e15 and without the exhaustive-kernel tuning bit; use SPT_ACCEL_BVH", c->n, SPT_MAX_SPHERES);
     if (c->mesh_scene || sphere_bvh) {
         uint64_t blocks = (uint64_t)c->cu_count * (c->blocks_per_cu ? c->blocks_per_cu : 4u);
         const uint64_t needed = (ntasks + 255) / 256;

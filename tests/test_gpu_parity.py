@@ -464,7 +464,15 @@ def test_error_behaviour(pkg):
     with pytest.raises(pkg.SptError, match="refl"):
         r.set_scene(bad)
     with pytest.raises(pkg.SptError, match="SPT_MAX_SPHERES"):
-        r.set_scene(np.zeros(5000, dtype=pkg.SPHERE_DTYPE))
+        r.set_scene(np.zeros(5000, dtype=pkg.SPHERE_DTYPE))            # radius 0: only the exhaustive kernels take it, and they hold 4096
+    r.set_sphere_accel(pkg.ACCEL_EXHAUSTIVE)
+    with pytest.raises(pkg.SptError, match="SPT_MAX_SPHERES"):
+        r.set_scene(pkg.random_spheres(5000, 1))
+    r.set_sphere_accel(pkg.ACCEL_GRID)
+    r.set_scene(pkg.random_spheres(5000, 1))                           # ... behind a structure it is fine
+    with pytest.raises(pkg.SptError, match="SPT_MAX_SPHERES"):
+        r.set_sphere_accel(pkg.ACCEL_EXHAUSTIVE)
+    r.set_scene(pkg.cornell9())
     import torch
     t = torch.empty((4, 8, 3), dtype=torch.float32, device="cuda:0")
     with pytest.raises(pkg.SptError, match="outside image"):

@@ -102,13 +102,16 @@ def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle):
               ("open 257", _cluster_scene(pkg, 257, 8, huge=False)), ("config 5", pkg.random_spheres(1024, 1024)), ("random 4096", pkg.random_spheres(4096, 7)),
               ("identical 50", pkg.make_spheres([(1.0, (50, 40, 80), (1, 1, 1), (.5, .5, .5), 0)] * 50)),
               # some of these 4096 are concentric with the wall spheres (centres 1e5 away): the extent is 1e5 long, nearly everything
-              # shares a cell, and the library keeps the exhaustive kernel for it (spt_api.cpp build_sphere_grid_tables)
-              ("cluster 4096", _cluster_scene(pkg, 4096, 9))]
+              # shares a cell, the grid declines (spt_api.cpp build_sphere_grid_tables) and from 1024 spheres on the hierarchy takes over
+              ("cluster 4096", _cluster_scene(pkg, 4096, 9)),
+              # sphere records beyond one CU's LDS: the hierarchy by default
+              ("random 12000", pkg.random_spheres(12000, 11))]
+    expect = {"cluster 4096": "sbvh", "random 12000": "sbvh"}
     for name, sc in scenes:
         w, h, samps, seed = (40, 30, 2, 3) if len(sc) < 600 else (32, 20, 1, 4)
         renderer.set_scene(sc)
         img, st = renderer.render(w, h, samps, seed=seed)
-        assert renderer.last_kernel() == ("mega" if name == "cluster 4096" else "grid"), name
+        assert renderer.last_kernel() == expect.get(name, "grid"), name
         ref, rst = oracle.render(sc, w, h, samps, seed=seed)
         assert np.array_equal(img, ref), (name, int((img != ref).any(axis=-1).sum()))
         assert st["bounces"] == rst["bounces"] and st["max_depth_kills"] == rst["max_depth_kills"], name

@@ -14,12 +14,15 @@ r.set_watchdog(120.0)
 rows = []
 for name, sc, w, h, samps, check_rows in (("config 5: 1024 spheres", pkg.random_spheres(1024, 1024), 1024, 768, 256, [100, 500]),
                                           ("4096 spheres", pkg.random_spheres(4096, 7), 1024, 768, 64, [300]),
-                                          ("300 clustered spheres (sizes 0.03 .. 6, overlapping, some concentric)", None, 1024, 768, 64, [300])):
-    if sc is None:
+                                          ("300 clustered spheres (sizes 0.03 .. 6, overlapping, some concentric)", None, 1024, 768, 64, [300]),
+                                          ("16384 spheres (records beyond one CU's LDS: the default mode falls to the hierarchy)", pkg.random_spheres(16384, 5), 1024, 768, 16, [300])):
+    if sc is None and name.startswith("300"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_sphere_accel import _cluster_scene
         sc = _cluster_scene(pkg, 300, 1)
     for accel in (pkg.ACCEL_EXHAUSTIVE, pkg.ACCEL_BVH, pkg.ACCEL_GRID):
+        if accel == pkg.ACCEL_EXHAUSTIVE and len(sc) > 4096:        # SPT_MAX_SPHERES: the exhaustive kernels stage the table in LDS
+            continue
         r.set_sphere_accel(accel)
         r.set_scene(sc)
         img, st = r.render(w, h, samps, seed=0, normalise=True)
