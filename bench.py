@@ -100,7 +100,7 @@ def interactive(pkg, r, dev, frames=600):
     # the product's own host: the C++ render loop (host/viewer.cpp, spt_progressive_frame / _frame_async behind the C-ABI) through the CLI
     cpp = {}
     cli = os.path.join(ROOT, "optix-test-smallpt_amd", "host", "smallpt_mi355x")
-    if os.path.exists(cli):
+    if os.path.exists(cli) and not os.environ.get("SPT_BENCH_NO_CPP"):    # (kernel A/B runs select the library with SPT_LIB, which the CLI does not read)
         import subprocess
         for lanes in (1, 2, 4, 8):
             try:

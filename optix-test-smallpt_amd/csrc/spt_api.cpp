@@ -93,6 +93,14 @@ struct spt_ctx {
     // tuning
     uint32_t blocks_per_cu = 0;
     uint32_t variant = 0;
+    // pool kernel, cost-ordered dispatch (spt_kernel.h KParams::chunk_order): tables of the last pool launch and the view they belong to
+    uint32_t* d_chunk_tables = nullptr;   // order[cap] | clock[2 * cap]
+    size_t chunk_cap = 0;
+    bool order_valid = false;
+    std::vector<unsigned char> order_key;  // camera, image, band, samples, scene generation: an identical next launch reuses the order
+    uint64_t scene_gen = 0;
+    hipEvent_t ev_order = nullptr;         // the order kernel of the last pool launch has run (the next launch may come on another stream)
+    bool order_pending = false;
     unsigned long long watchdog_ticks = 0;   // pool kernel: s_memtime ticks (shader cycles) per launch; 0 = no watchdog
     // last launch
     bool pending = false;
@@ -163,6 +171,7 @@ int spt_create(int device_id, spt_ctx** out)
     if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev_mid)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     void* p = nullptr;
     if ((e = hipMalloc(&p, 256)) != hipSuccess) return bail("hipMalloc", e);
     c->d_queue = static_cast<uint32_t*>(p);
@@ -176,6 +185,7 @@ void spt_destroy(spt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_mat) (void)hipFree(c->d_mat);
     if (c->d_cells) (void)hipFree(c->d_cells);
@@ -207,6 +217,7 @@ void spt_destroy(spt_ctx* c)
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->ev_acc) (void)hipEventDestroy(c->ev_acc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -292,6 +303,7 @@ static int set_scene_impl(spt_ctx* c, const spt_sphere* s, uint32_t n)
     SPT_HIP(c, hipMemcpy(c->d_geom, geom.data(), sizeof(float4) * cap, hipMemcpyHostToDevice));
     SPT_HIP(c, hipMemcpy(c->d_mat, mat.data(), sizeof(float4) * 3 * cap, hipMemcpyHostToDevice));
     c->n = n;
+    ++c->scene_gen;
     c->mesh_scene = false;
     c->h_geom.assign(geom.begin(), geom.begin() + n);
     c->h_radius.resize(n);
@@ -903,12 +915,49 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         P.stack = c->d_stack;
         P.slot_state = reinterpret_cast<uint2*>(c->d_stack + stack_floats);
         P.watchdog_ticks = c->watchdog_ticks;
+        // Cost-ordered dispatch: the queue hands out chunks of 64 tasks; every launch records how long each chunk kept its wave
+        // busy, and a launch of the SAME view (scene, camera, image, band, samples -- the viewer's frames, a repeated render; the seed
+        // may differ, a pixel's cost is a property of what it looks at) starts the expensive chunks first.  Results do not depend on
+        // the dispatch order.  Tuning bit 13 switches it off for this kernel (A/B).
+        const uint32_t nchunks = (uint32_t)((ntasks + 63) / 64);
+        std::vector<unsigned char> key(sizeof(spt_camera) + 10 * sizeof(uint32_t) + sizeof(uint64_t));
+        {
+            unsigned char* k = key.data();
+            std::memcpy(k, cam, sizeof(spt_camera)); k += sizeof(spt_camera);
+            const uint32_t words[10] = {w, h, row_begin, row_count, rb_log2, rb_stride, rb_mask, samps, c->variant, (uint32_t)blocks};
+            std::memcpy(k, words, sizeof words); k += sizeof words;
+            std::memcpy(k, &c->scene_gen, sizeof(uint64_t));
+        }
+        if (c->order_pending) { SPT_HIP(c, hipStreamWaitEvent(st, c->ev_order, 0)); c->order_pending = false; }
+        // (not for the viewer's frames of a few samples per cell: a chunk's time is then the luck of 64 single paths, and the order kernel
+        // between two frames costs the frames in flight more than it gains; bit 13 means something else to the grid kernel only)
+        if (!(c->variant & 0x2000u) && samps >= 16u) {
+            if (nchunks > c->chunk_cap) {
+                if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
+                c->d_chunk_tables = nullptr; c->chunk_cap = 0; c->order_valid = false;
+                SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_chunk_tables), (size_t)nchunks * 3 * sizeof(uint32_t)));
+                c->chunk_cap = nchunks;
+            }
+            uint32_t* const d_order = c->d_chunk_tables;
+            uint32_t* const d_clock = c->d_chunk_tables + c->chunk_cap;
+            P.chunk_order = (c->order_valid && key == c->order_key) ? d_order : nullptr;
+            P.chunk_clock = d_clock;
+            P.nchunks = nchunks;
+            SPT_HIP(c, hipMemsetAsync(d_clock + nchunks, 0, (size_t)nchunks * sizeof(uint32_t), st));
+        }
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));
         SPT_HIP(c, spt_pool_launch(&P, (uint32_t)blocks, pool, st));
         SPT_HIP(c, hipEventRecord(c->ev_mid, st));
         SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
+        if (P.chunk_clock) {                                         // (after ev_stop: not part of the frame's device time, overlaps the caller's next step)
+            SPT_HIP(c, spt_pool_chunk_order(P.chunk_clock, nchunks, c->d_chunk_tables, st));
+            SPT_HIP(c, hipEventRecord(c->ev_order, st));
+            c->order_pending = true;
+            c->order_key.swap(key);
+            c->order_valid = true;
+        }
         c->pending = true;
         c->last_was_pool = true;
         c->last_kernel = 1;

@@ -39,6 +39,13 @@ struct KParams {
     // pool kernel (spt_pool.hip) only
     uint2* slot_state;             // waves x pool slots x {task id, next sample}
     unsigned long long watchdog_ticks;  // pool and grid kernels: s_memtime ticks after which a wave gives up (0 = never)
+    // pool kernel: cost-ordered dispatch (spt_pool.hip "chunk order").  The task queue hands out chunks of 64 consecutive task ids;
+    // chunk_clock[c] / chunk_clock[nchunks + c] receive the time chunk c was fetched / its last task was completed (s_memtime >> 6,
+    // the clock of the one wave that works on it), and chunk_order -- when not null -- is the permutation a previous launch of the
+    // same view derived from those: the queue's k-th chunk is chunk_order[k], most expensive first.
+    const uint32_t* chunk_order;
+    uint32_t* chunk_clock;
+    uint32_t nchunks;
 };
 
 // Triangle-mesh scene (spt_mesh.hip): the reference's TriMesh instances flattened into device tables
@@ -77,6 +84,7 @@ extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block);
 extern "C" size_t spt_k_stack_floats(uint32_t blocks, int block_threads);
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream);
+extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t* chunk_order, hipStream_t stream);
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream);
 extern "C" int spt_k_block_threads(void);
 extern "C" int spt_k_block_threads_for(int mat_lds, int big_block);

@@ -126,14 +126,23 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
     uint32_t nkill = 0;                                          // per lane
     uint32_t nrec = 0;                                           // per lane: pending-child records written
     uint32_t itG = 0, itD = 0, itR = 0;                          // batches per class (utilisation report)
-    unsigned long long lnG = 0, lnD = 0, lnR = 0;                // lanes per class
+    uint32_t lnG = 0, lnD = 0, lnR = 0;                          // lanes per class (32 bits per wave: scalar registers are scarce in this loop)
     uint32_t itTail = 0, itFull = 0;                             // batches after the task queue ran dry / full batches
-    unsigned long long lnTail = 0;
+    uint32_t lnTail = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     uint32_t it_total = 0;
     bool timed_out = false;
     uint32_t dry_lo = 0, dry_hi = 0;                             // when this wave found the task queue empty: written once, read once,
                                                                  // so parked in vector registers rather than in scarce scalar ones
+    // The tables of the cost-ordered dispatch are parked there too (5 registers of 30 spare ones).  In scalar registers they cost the
+    // loop 20 spills; re-read from the kernel-argument segment where they are used, the compiler also re-reads other arguments
+    // there, and a scalar load that may still be in flight when the closest-hit code is reached (they return out of order) turns
+    // its counted waits on the sphere records -- lgkmcnt(5), (4), ... -- into one wait for all of them: 2.8 % of the launch.
+    uint32_t ord_lo, ord_hi, clk_lo, clk_hi, nch_v;
+    asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
+                 : "=v"(ord_lo), "=v"(ord_hi), "=v"(clk_lo), "=v"(clk_hi), "=v"(nch_v)
+                 : "s"((uint32_t)(uintptr_t)K.chunk_order), "s"((uint32_t)((uintptr_t)K.chunk_order >> 32)),
+                   "s"((uint32_t)(uintptr_t)K.chunk_clock), "s"((uint32_t)((uintptr_t)K.chunk_clock >> 32)), "s"(K.nchunks));
 
 #ifdef SPT_POOL_PHASES
     unsigned long long ph[5] = {0, 0, 0, 0, 0};                  // select+pop, class code, closest hit, post, push (lone-path latency study)
@@ -208,7 +217,22 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
             }
             const unsigned long long need_mask = __ballot(need_task);
             if (need_mask != 0ull) {
-                if (need_task && task != kNoTask) K.cells[task] = make_float4(ACX[slot], ACY[slot], ACZ[slot], 0.0f);
+                // cost-ordered dispatch (see chunk_order_kernel): completion times go to the chunk's clock word, fetch times below
+                // (pointers rebuilt from integers are generic to the compiler: said to be global, or it emits FLAT operations, which count
+                // on lgkmcnt as well and take the counted waits of the closest-hit code with them)
+                typedef __attribute__((address_space(1))) uint32_t* GWords;
+                uint32_t c_lo = clk_lo, c_hi = clk_hi, o_lo = ord_lo, o_hi = ord_hi;
+                asm volatile("" : "+v"(c_lo), "+v"(c_hi), "+v"(o_lo), "+v"(o_hi));      // (keeps the null tests here instead of in four scalar registers across the loop)
+                const GWords clk = (GWords)(((unsigned long long)c_hi << 32) | c_lo);
+                uint32_t now32;
+                {
+                    const unsigned long long t = __builtin_amdgcn_s_memtime();
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(now32) : "s"((uint32_t)(t >> 6)));    // consumed here: no scalar-memory result is left in flight
+                }
+                if (need_task && task != kNoTask) {
+                    K.cells[task] = make_float4(ACX[slot], ACY[slot], ACZ[slot], 0.0f);
+                    if (clk) (void)__hip_atomic_fetch_max(clk + nch_v + (task >> 6), now32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 // wave-private chunks of task ids; only the refill touches the global queue word
                 const uint32_t cntn = (uint32_t)__popcll(need_mask);
                 const uint32_t rk = rank_in(need_mask);
@@ -225,6 +249,10 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
                             queue_empty = true;
                             const unsigned long long t = __builtin_amdgcn_s_memtime();
                             asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(dry_lo), "=v"(dry_hi) : "s"((uint32_t)t), "s"((uint32_t)(t >> 32)));
+                        } else {
+                            const GWords ord = (GWords)(((unsigned long long)o_hi << 32) | o_lo);
+                            if (ord) base_new = uni(ord[base_new >> 6]) << 6;        // the queue's k-th chunk of 64 tasks (declared wave-uniform: the list arithmetic stays scalar)
+                            if (clk && (int)lane == leader) clk[base_new >> 6] = now32;
                         }
                     } else {
                         base_new = K.ntasks;                     // nothing left: ids >= ntasks mean "no task"
@@ -526,9 +554,9 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
         if (nk) atomicAdd(&K.counters[1], nk);
         atomicAdd(&K.counters[2], (unsigned long long)itG); atomicAdd(&K.counters[3], (unsigned long long)itD);
         atomicAdd(&K.counters[4], (unsigned long long)itR);
-        atomicAdd(&K.counters[5], lnG); atomicAdd(&K.counters[6], lnD); atomicAdd(&K.counters[7], lnR);
+        atomicAdd(&K.counters[5], (unsigned long long)lnG); atomicAdd(&K.counters[6], (unsigned long long)lnD); atomicAdd(&K.counters[7], (unsigned long long)lnR);
         if (timed_out) atomicAdd(&K.counters[8], 1ull);
-        atomicAdd(&K.counters[9], (unsigned long long)itTail); atomicAdd(&K.counters[10], lnTail);
+        atomicAdd(&K.counters[9], (unsigned long long)itTail); atomicAdd(&K.counters[10], (unsigned long long)lnTail);
         atomicAdd(&K.counters[11], (unsigned long long)itFull);
         // launch timeline in s_memtime ticks, wave-local differences only (the counter is not synchronised across XCDs):
         // longest wave, longest and summed time a wave kept running after it found the task queue empty
@@ -548,6 +576,41 @@ __global__ __launch_bounds__(kPoolBlock) void poolkernel(const KParams K)
 }  // namespace spt
 
 // LDS per 256-thread workgroup: four wave pools + the padded scene table (16 B geometry + 48 B material per sphere)
+namespace spt {
+// Chunk order for the next launch of the same view: chunks by the time their wave spent on them (fetch to last completion), longest
+// first -- 256 logarithmic buckets (8 per octave), one workgroup.  A launch ends on the blocks that were started last, and the cost of
+// a block varies by two orders of magnitude with the pixel (every sample of a pixel that looks at the mirror ball's contact point
+// runs ~1000 bounces: such a 32-sample block keeps one slot busy for ~20 ms of an 80 ms launch); started first, they end with the rest.
+// The order inside a bucket is whatever the atomics give: dispatch order never changes a result.
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t cost)
+{
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(cost | 1u);
+    const uint32_t frac = lg >= 3u ? (cost >> (lg - 3u)) & 7u : 0u;
+    return 255u - (lg * 8u + frac);
+}
+
+__global__ __launch_bounds__(1024) void chunk_order_kernel(const uint32_t* __restrict__ clock, uint32_t n, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[256];
+    if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t run = 0u;
+        for (int b = 0; b < 256; ++b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) order[atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u)] = i;
+}
+}  // namespace spt
+
+extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t* chunk_order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(spt::chunk_order_kernel, dim3(1), dim3(1024), 0, stream, chunk_clock, nchunks, chunk_order);
+    return hipGetLastError();
+}
+
 extern "C" size_t spt_pool_lds_bytes(uint32_t n, int pool)
 {
     const uint32_t ng = n == 0 ? 1u : (n + 2u) / 3u;

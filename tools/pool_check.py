@@ -28,7 +28,8 @@ def pool_report(r, st):
             f"{[round(l / max(i, 1), 1) for l, i in zip(ln, it)]} overall fill {tot_ln / max(tot_it, 1) / 64:.3f} "
             f"full batches {d[9] / max(tot_it, 1):.3f} tail batches {d[7] / max(tot_it, 1):.3f} tail fill {d[8] / max(d[7], 1) / 64:.3f} "
             f"pre-tail fill {(tot_ln - d[8]) / max(tot_it - d[7], 1) / 64:.3f} "
-            f"| pending-child records {d[14]} ({d[14] / max(st['samples'], 1):.4f} per sample)")
+            f"| pending-child records {d[14]} ({d[14] / max(st['samples'], 1):.4f} per sample) | bounces shaded in solo mode {d[21]}"
+            + (f" | wave with the longest drain: {(d[22] >> 40) * 256 / 2.4e6:.2f} ms, {(d[22] >> 20) & 0xFFFFF} batches after dry, {d[22] & 0xFFFFF} lanes, last task {d[23] & 0xFFFFFFFF}" if d[22] else ""))
 
 
 def main():
