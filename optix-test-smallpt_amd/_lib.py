@@ -83,6 +83,7 @@ INTERNAL_SYMBOLS = {
     "spt_selftest_range": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "spt_set_watchdog": (C.c_int, [_P, C.c_double]),
     "spt_last_kernel": (C.c_int, [_P]),
+    "spt_chunk_order_snapshot": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 }
 
 class SptMultiStats(C.Structure):

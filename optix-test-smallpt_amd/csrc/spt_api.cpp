@@ -99,6 +99,7 @@ struct spt_ctx {
     bool order_valid = false;
     std::vector<unsigned char> order_key;  // camera, image, band, samples, scene generation: an identical next launch reuses the order
     uint64_t scene_gen = 0;
+    uint32_t last_nchunks = 0;             // chunks of the launch the order table was derived from (0: that launch recorded none)
     hipEvent_t ev_order = nullptr;         // the order kernel of the last pool launch has run (the next launch may come on another stream)
     bool order_pending = false;
     unsigned long long watchdog_ticks = 0;   // pool kernel: s_memtime ticks (shader cycles) per launch; 0 = no watchdog
@@ -952,11 +953,14 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
         if (P.chunk_clock) {                                         // (after ev_stop: not part of the frame's device time, overlaps the caller's next step)
-            SPT_HIP(c, spt_pool_chunk_order(P.chunk_clock, nchunks, c->d_chunk_tables, st));
+            SPT_HIP(c, spt_pool_chunk_order(P.chunk_clock, nchunks, (uint32_t)ntasks, c->d_chunk_tables, st));
             SPT_HIP(c, hipEventRecord(c->ev_order, st));
             c->order_pending = true;
             c->order_key.swap(key);
             c->order_valid = true;
+            c->last_nchunks = nchunks;
+        } else {
+            c->last_nchunks = 0;
         }
         c->pending = true;
         c->last_was_pool = true;
@@ -1180,6 +1184,19 @@ int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
 }
 
 // Diagnostic (tuning variant bit 8): per-phase wave-time sums [0..7], iterations, lane counts of the last launch.
+int spt_chunk_order_snapshot(spt_ctx* c, uint32_t* order, uint32_t cap, uint32_t* nchunks)
+{
+    if (!c || !nchunks) return 1;
+    *nchunks = 0;
+    if (!c->order_valid || !c->last_was_pool || c->last_nchunks == 0) return 0;
+    if (!order || cap < c->last_nchunks) return c->fail("spt_chunk_order_snapshot: room for %u words, the order has %u", cap, c->last_nchunks);
+    SPT_HIP(c, hipSetDevice(c->device));
+    if (c->order_pending) SPT_HIP(c, hipEventSynchronize(c->ev_order));
+    SPT_HIP(c, hipMemcpy(order, c->d_chunk_tables, (size_t)c->last_nchunks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *nchunks = c->last_nchunks;
+    return 0;
+}
+
 int spt_diag(spt_ctx* c, unsigned long long* out24)
 {
     if (!c || !out24) return 1;

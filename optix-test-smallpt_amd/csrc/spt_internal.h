@@ -19,6 +19,12 @@ extern "C" {
  * 1 + q, a wave leaves its walk phase when 16 x walking lanes < q x waiting lanes (0 = default q = 16), bits 31:24 = grid cells per sphere
  * (read by spt_set_scene; 0 = default 4).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
+/* Pool kernel: bit 13 = hand the task chunks out in their static order (no cost-ordered dispatch, spt_kernel.h KParams::chunk_order; the
+ * grid kernel reads bits 15:13 as its workgroup size). */
+/* Pool kernel, cost-ordered dispatch: copies the chunk order that the last pool launch left for the next launch of the same view
+ * (a permutation of 0 .. nchunks - 1, most expensive chunk first) to `order` (room for `cap` words).  *nchunks = 0 when that
+ * launch recorded none (a few samples per cell, tuning bit 13, another kernel).  Synchronises with the device. */
+int  spt_chunk_order_snapshot(spt_ctx* ctx, uint32_t* order, uint32_t cap, uint32_t* nchunks);
 /* Diagnostics of the last launch when variant bit 8 selected the instrumented kernel build:
  * out24[0..7] = wave-time (shader clocks) per phase, [8] iterations, [9..14] lane/run counters (24 words are written). */
 int  spt_diag(spt_ctx* ctx, unsigned long long* out24);

@@ -589,25 +589,29 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t cost)
     return 255u - (lg * 8u + frac);
 }
 
-__global__ __launch_bounds__(1024) void chunk_order_kernel(const uint32_t* __restrict__ clock, uint32_t n, uint32_t* __restrict__ order)
+// n chunks, the first `sorted` of them ordered (the last chunk of a task count that is no multiple of 64 stays last: a slot that is
+// handed an id beyond the last task retires for the rest of the launch).
+__global__ __launch_bounds__(1024) void chunk_order_kernel(const uint32_t* __restrict__ clock, uint32_t n, uint32_t sorted, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t hist[256];
     if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u);
+    for (uint32_t i = threadIdx.x; i < sorted; i += 1024u) atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u);
     __syncthreads();
     if (threadIdx.x == 0u) {
         uint32_t run = 0u;
         for (int b = 0; b < 256; ++b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) order[atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u)] = i;
+    for (uint32_t i = threadIdx.x; i < sorted; i += 1024u) order[atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u)] = i;
+    for (uint32_t i = sorted + threadIdx.x; i < n; i += 1024u) order[i] = i;
 }
 }  // namespace spt
 
-extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t* chunk_order, hipStream_t stream)
+extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t ntasks, uint32_t* chunk_order, hipStream_t stream)
 {
-    hipLaunchKernelGGL(spt::chunk_order_kernel, dim3(1), dim3(1024), 0, stream, chunk_clock, nchunks, chunk_order);
+    const uint32_t sorted = (ntasks & 63u) != 0u && nchunks > 0u ? nchunks - 1u : nchunks;
+    hipLaunchKernelGGL(spt::chunk_order_kernel, dim3(1), dim3(1024), 0, stream, chunk_clock, nchunks, sorted, chunk_order);
     return hipGetLastError();
 }
 

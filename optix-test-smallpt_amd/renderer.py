@@ -221,6 +221,15 @@ class Renderer:
         self._check(self._lib.spt_diag(self._h, C.byref(arr)))
         return [int(v) for v in arr]
 
+    def chunk_order(self):
+        """The pool kernel's chunk order for the next launch of the same view (spt_chunk_order_snapshot): a permutation of the
+        64-task chunks, most expensive first; empty when the last launch recorded none."""
+        cap = 1 << 22
+        buf = np.empty(cap, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._check(self._lib.spt_chunk_order_snapshot(self._h, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return buf[:n.value].copy()
+
     def selftest_math(self, op, x, w=1024):
         """Runs device helper `op` over the float32 array x (see spt_selftest_math)."""
         x = np.ascontiguousarray(x, dtype=np.float32)

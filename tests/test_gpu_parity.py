@@ -452,6 +452,42 @@ def test_kernel_watchdog_reports_instead_of_hanging(pkg):
     r.close()
 
 
+def test_cost_ordered_dispatch_changes_no_bit(pkg, oracle):
+    """Pool kernel, cost-ordered dispatch (spt_api.cpp: a launch records how long each chunk of 64 tasks kept its wave busy, the next
+    launch of the same view hands the expensive chunks out first): the order is a permutation that keeps the partial last chunk last,
+    launches that use it -- same seed, another seed, a changed camera in between -- equal the oracle bit for bit with equal
+    bounce counts, and so does the static order (tuning bit 13)."""
+    r = pkg.Renderer(0)
+    r.set_watchdog(20.0)
+    r.set_scene(pkg.cornell9())
+    w, h, samps = 37, 53, 16                                         # 7844 tasks: 122 full chunks + one of 36 tasks
+    ntasks = w * h * 4
+    refs = {seed: oracle.render(pkg.cornell9(), w, h, samps, seed=seed, normalise=True) for seed in (3, 4)}
+    assert len(r.chunk_order()) == 0                                 # nothing rendered yet
+    for seed in (3, 3, 4, 3):                                        # the first launch has no history, the others run in the order their predecessor left
+        img, st = r.render(w, h, samps, seed=seed, normalise=True)
+        assert r.last_kernel() == "pool"
+        ref, rst = refs[seed]
+        assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"], seed
+        order = r.chunk_order()
+        assert len(order) == (ntasks + 63) // 64 and np.array_equal(np.sort(order), np.arange(len(order)))
+        assert order[-1] == len(order) - 1 and ntasks % 64 != 0
+    cam = pkg.pinhole_camera()
+    img, st = r.render(w, h, samps, seed=3, normalise=True, camera=cam)            # another view: static order, new history
+    ref, rst = oracle.render(pkg.cornell9(), w, h, samps, seed=3, normalise=True, camera=cam)
+    assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+    img, st = r.render(w, h, samps, seed=4, normalise=True, camera=cam)
+    ref, rst = oracle.render(pkg.cornell9(), w, h, samps, seed=4, normalise=True, camera=cam)
+    assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+    r.set_tuning(0, 0x2000)                                          # static order: records nothing
+    img, st = r.render(w, h, samps, seed=3, normalise=True)
+    assert np.array_equal(img, refs[3][0]) and len(r.chunk_order()) == 0
+    r.set_tuning(0, 0)
+    img, st = r.render(w, h, 1, seed=3, normalise=True)              # a viewer frame: too few samples per cell to be worth an order
+    assert len(r.chunk_order()) == 0
+    r.close()
+
+
 def test_error_behaviour(pkg):
     r = pkg.Renderer(0)
     with pytest.raises(pkg.SptError, match="no scene"):
