@@ -94,7 +94,7 @@ struct spt_ctx {
     uint32_t blocks_per_cu = 0;
     uint32_t variant = 0;
     // pool kernel, cost-ordered dispatch (spt_kernel.h KParams::chunk_order): tables of the last pool launch and the view they belong to
-    uint32_t* d_chunk_tables = nullptr;   // order[cap] | clock[2 * cap]
+    uint32_t* d_chunk_tables = nullptr;   // order[cap] | clock[2 * cap] | 512 words of the sorting kernels
     size_t chunk_cap = 0;
     bool order_valid = false;
     std::vector<unsigned char> order_key;  // camera, image, band, samples, scene generation: an identical next launch reuses the order
@@ -936,7 +936,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
             if (nchunks > c->chunk_cap) {
                 if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
                 c->d_chunk_tables = nullptr; c->chunk_cap = 0; c->order_valid = false;
-                SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_chunk_tables), (size_t)nchunks * 3 * sizeof(uint32_t)));
+                SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_chunk_tables), ((size_t)nchunks * 3 + 512) * sizeof(uint32_t)));
                 c->chunk_cap = nchunks;
             }
             uint32_t* const d_order = c->d_chunk_tables;
@@ -953,7 +953,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
         if (P.chunk_clock) {                                         // (after ev_stop: not part of the frame's device time, overlaps the caller's next step)
-            SPT_HIP(c, spt_pool_chunk_order(P.chunk_clock, nchunks, (uint32_t)ntasks, c->d_chunk_tables, st));
+            SPT_HIP(c, spt_pool_chunk_order(P.chunk_clock, nchunks, (uint32_t)ntasks, c->d_chunk_tables, c->d_chunk_tables + 3 * c->chunk_cap, st));
             SPT_HIP(c, hipEventRecord(c->ev_order, st));
             c->order_pending = true;
             c->order_key.swap(key);

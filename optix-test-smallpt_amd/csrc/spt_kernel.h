@@ -84,7 +84,7 @@ extern "C" hipError_t spt_mesh_trace_rays(const spt::MParams* M, const float* d_
 extern "C" size_t spt_k_lds_bytes(uint32_t n_pad, int mat_lds, int big_block);
 extern "C" size_t spt_k_stack_floats(uint32_t blocks, int block_threads);
 extern "C" hipError_t spt_k_launch(const spt::KParams* P, uint32_t blocks, int mat_lds, int guard, int diag, int bign, int big_block, hipStream_t stream);
-extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t ntasks, uint32_t* chunk_order, hipStream_t stream);
+extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t ntasks, uint32_t* chunk_order, uint32_t* work512, hipStream_t stream);
 extern "C" hipError_t spt_k_finalize(const float4* cells, float* out, uint32_t npix, float scale, int normalise, uint32_t nb, hipStream_t stream);
 extern "C" int spt_k_block_threads(void);
 extern "C" int spt_k_block_threads_for(int mat_lds, int big_block);

@@ -590,28 +590,60 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t cost)
 }
 
 // n chunks, the first `sorted` of them ordered (the last chunk of a task count that is no multiple of 64 stays last: a slot that is
-// handed an id beyond the last task retires for the rest of the launch).
-__global__ __launch_bounds__(1024) void chunk_order_kernel(const uint32_t* __restrict__ clock, uint32_t n, uint32_t sorted, uint32_t* __restrict__ order)
+// handed an id beyond the last task retires for the rest of the launch).  Three small launches over slices of kOrderSlice chunks --
+// bucket counts, their prefix sums, scatter; `work` = 256 global counters + 256 offsets -- 15 us for the
+// 393 216 chunks of config 2 (one workgroup doing all of it with LDS atomics took 350 us, behind every launch).
+constexpr uint32_t kOrderSlice = 4096;
+
+__global__ __launch_bounds__(1024) void chunk_count_kernel(const uint32_t* __restrict__ clock, uint32_t n, uint32_t sorted, uint32_t* __restrict__ work)
 {
     __shared__ uint32_t hist[256];
     if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < sorted; i += 1024u) atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u);
+    const uint32_t first = blockIdx.x * kOrderSlice, last = first + kOrderSlice < sorted ? first + kOrderSlice : sorted;
+    for (uint32_t i = first + threadIdx.x; i < last; i += 1024u) atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 256u && hist[threadIdx.x]) atomicAdd(&work[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void chunk_scan_kernel(uint32_t* __restrict__ work)
+{
+    __shared__ uint32_t cnt[256];
+    cnt[threadIdx.x] = work[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0u) {
         uint32_t run = 0u;
-        for (int b = 0; b < 256; ++b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+        for (int b = 0; b < 256; ++b) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < sorted; i += 1024u) order[atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u)] = i;
-    for (uint32_t i = sorted + threadIdx.x; i < n; i += 1024u) order[i] = i;
+    work[256 + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void chunk_scatter_kernel(const uint32_t* __restrict__ clock, uint32_t n, uint32_t sorted, uint32_t* __restrict__ work,
+                                                             uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[256];
+    if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * kOrderSlice, last = first + kOrderSlice < sorted ? first + kOrderSlice : sorted;
+    for (uint32_t i = first + threadIdx.x; i < last; i += 1024u) atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 256u) { const uint32_t c = hist[threadIdx.x]; hist[threadIdx.x] = c ? atomicAdd(&work[256 + threadIdx.x], c) : 0u; }   // this slice's range in every bucket
+    __syncthreads();
+    for (uint32_t i = first + threadIdx.x; i < last; i += 1024u) order[atomicAdd(&hist[cost_bucket(clock[n + i] - clock[i])], 1u)] = i;
+    if (blockIdx.x == 0u) for (uint32_t i = sorted + threadIdx.x; i < n; i += 1024u) order[i] = i;
 }
 }  // namespace spt
 
-extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t ntasks, uint32_t* chunk_order, hipStream_t stream)
+extern "C" hipError_t spt_pool_chunk_order(const uint32_t* chunk_clock, uint32_t nchunks, uint32_t ntasks, uint32_t* chunk_order, uint32_t* work512, hipStream_t stream)
 {
     const uint32_t sorted = (ntasks & 63u) != 0u && nchunks > 0u ? nchunks - 1u : nchunks;
-    hipLaunchKernelGGL(spt::chunk_order_kernel, dim3(1), dim3(1024), 0, stream, chunk_clock, nchunks, sorted, chunk_order);
+    const uint32_t slices = sorted ? (sorted + spt::kOrderSlice - 1u) / spt::kOrderSlice : 1u;
+    hipError_t e = hipMemsetAsync(work512, 0, 256 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spt::chunk_count_kernel, dim3(slices), dim3(1024), 0, stream, chunk_clock, nchunks, sorted, work512);
+    hipLaunchKernelGGL(spt::chunk_scan_kernel, dim3(1), dim3(256), 0, stream, work512);
+    hipLaunchKernelGGL(spt::chunk_scatter_kernel, dim3(slices), dim3(1024), 0, stream, chunk_clock, nchunks, sorted, work512, chunk_order);
     return hipGetLastError();
 }
 
