@@ -190,7 +190,10 @@ int  spt_render(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
  * (a hipStream_t cast to void*; NULL = the context's own stream) and returns without waiting for it
  * (a context keeps one launch in flight: a call made while the previous launch is still running first waits for it).
  * Pixel/sample RNG keys use the GLOBAL pixel index, so any row partition over any number of GPUs
- * yields the same image.  Call spt_sync() before reading stats. */
+ * yields the same image.  Call spt_sync() before reading stats.
+ * Scheduling only (never the result): for tables of <= 24 spheres and >= 16 samples per cell a context remembers how long each group
+ * of sample blocks took in its last launch, and a launch of the same scene, camera, image, band and sample count (any seed) starts the
+ * expensive ones first -- a view's second and later launches are ~5 % shorter at 1024 spp than its first. */
 int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
                             uint32_t row_begin, uint32_t row_count,
                             uint32_t samps_per_cell, uint64_t seed, uint32_t flags,
