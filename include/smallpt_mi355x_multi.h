@@ -80,6 +80,19 @@ int  spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t 
 /* Device pointer (root device) of the framebuffer assembled by the last spt_multi_render: w*h*3 floats. */
 void* spt_multi_framebuffer(spt_multi* m);
 
+/* The viewer's render loop (smallpt.cpp:895-942) over all devices, the counterpart of spt_progressive_* (include/smallpt_mi355x.h):
+ *   _begin     allocates accumBuffer (w*h*3 floats, zeroed) on the root device;
+ *   _frame     = `outImage = renderer.render(camera, ..., seed)` (:922) on all devices, assembled on the root, followed by
+ *                accumBuffer = outImage (clear != 0: the frame after a request, :924-930) or accumBuffer += outImage (:932-937) there;
+ *                frames are raw sums (no division by spp), as Renderer::render returns them;
+ *   _snapshot  = `image = accumBuffer` under the mutex (:955-959): copies accumBuffer to w*h*3 host floats;
+ *   _end       frees accumBuffer.
+ * One frame at a time (a frame in flight on every device already fills the node). */
+int  spt_multi_progressive_begin(spt_multi* m, uint32_t w, uint32_t h);
+int  spt_multi_progressive_frame(spt_multi* m, const spt_camera* cam, uint32_t samps_per_cell, uint64_t seed, int clear, spt_multi_stats* stats);
+int  spt_multi_progressive_snapshot(spt_multi* m, float* out_rgb);
+int  spt_multi_progressive_end(spt_multi* m);
+
 #ifdef __cplusplus
 }
 #endif

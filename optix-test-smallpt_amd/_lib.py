@@ -107,6 +107,10 @@ MULTI_SYMBOLS = {
     "spt_multi_render": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                    C.c_uint32, _P, C.POINTER(SptMultiStats)]),
     "spt_multi_framebuffer": (_P, [_P]),
+    "spt_multi_progressive_begin": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "spt_multi_progressive_frame": (C.c_int, [_P, C.POINTER(SptCamera), C.c_uint32, C.c_uint64, C.c_int, C.POINTER(SptMultiStats)]),
+    "spt_multi_progressive_snapshot": (C.c_int, [_P, _P]),
+    "spt_multi_progressive_end": (C.c_int, [_P]),
 }
 
 MULTI_INTERNAL_SYMBOLS = {"spt_multi_set_rank_watchdog": (C.c_int, [_P, C.c_uint32, C.c_double])}   # csrc/spt_internal.h

@@ -101,6 +101,8 @@ struct spt_multi {
     size_t frame_cap = 0;
     float* d_staging = nullptr;    // root device, interleaved partition: the other ranks' packed rows before the scatter
     size_t staging_cap = 0;
+    float* d_accum = nullptr;      // root device: accumBuffer of the progressive loop (spt_multi_progressive_*), w*h*3 floats
+    uint32_t prog_w = 0, prog_h = 0;
     std::string error;
 
     int fail(const char* fmt, ...)
@@ -162,6 +164,7 @@ void spt_multi_destroy(spt_multi* m)
             if (r.d_band) (void)hipFree(r.d_band);
             if (i == 0 && m->d_frame) (void)hipFree(m->d_frame);
             if (i == 0 && m->d_staging) (void)hipFree(m->d_staging);
+            if (i == 0 && m->d_accum) (void)hipFree(m->d_accum);
             if (r.ev_a) (void)hipEventDestroy(r.ev_a);
             if (r.ev_b) (void)hipEventDestroy(r.ev_b);
             if (r.stream) (void)hipStreamDestroy(r.stream);
@@ -471,6 +474,72 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
     } catch (const std::exception& e) {
         return m->fail("spt_multi_render: %s", e.what());
     }
+}
+
+// ---- the viewer's render loop over several devices (smallpt.cpp:895-942): accumBuffer lives on the root device ----
+static int on_root(spt_multi* m, const std::function<void(Rank&)>& fn)
+{
+    Rank& r0 = m->ranks[0];
+    r0.error.clear();
+    r0.worker->submit([&] { fn(r0); });
+    r0.worker->wait();
+    if (!r0.error.empty()) return m->fail("device %d: %s", r0.device, r0.error.c_str());
+    return 0;
+}
+
+int spt_multi_progressive_begin(spt_multi* m, uint32_t w, uint32_t h)
+{
+    if (!m) return 1;
+    if (w == 0 || h == 0) return m->fail("spt_multi_progressive_begin: empty image");
+    const size_t bytes = (size_t)w * h * 3 * sizeof(float);
+    const int rc = on_root(m, [&](Rank& r) {
+        RK_HIP(r, hipSetDevice(r.device));
+        if (m->d_accum) (void)hipFree(m->d_accum);
+        m->d_accum = nullptr;
+        RK_HIP(r, hipMalloc(reinterpret_cast<void**>(&m->d_accum), bytes));
+        RK_HIP(r, hipMemset(m->d_accum, 0, bytes));
+    });
+    if (rc == 0) { m->prog_w = w; m->prog_h = h; }
+    return rc;
+}
+
+int spt_multi_progressive_frame(spt_multi* m, const spt_camera* cam, uint32_t samps, uint64_t seed, int clear, spt_multi_stats* stats)
+{
+    if (!m) return 1;
+    if (!m->d_accum) return m->fail("spt_multi_progressive_frame: call spt_multi_progressive_begin first");
+    // outImage = renderer.render(...) (:922) on all devices, assembled on the root; then accumBuffer (+)= outImage (:924-937) there
+    int rc = spt_multi_render(m, cam, m->prog_w, m->prog_h, samps, seed, 0u, nullptr, stats);
+    if (rc != 0) return rc;
+    const uint64_t n = (uint64_t)m->prog_w * m->prog_h * 3;
+    return on_root(m, [&](Rank& r) {
+        RK_HIP(r, hipSetDevice(r.device));
+        if (spt_accumulate_device(r.ctx, m->d_accum, m->d_frame, n, clear, r.stream) != 0) { r.error = spt_last_error(r.ctx); return; }
+        RK_HIP(r, hipStreamSynchronize(r.stream));
+    });
+}
+
+int spt_multi_progressive_snapshot(spt_multi* m, float* out_rgb)
+{
+    if (!m) return 1;
+    if (!m->d_accum) return m->fail("spt_multi_progressive_snapshot: call spt_multi_progressive_begin first");
+    if (!out_rgb) return m->fail("spt_multi_progressive_snapshot: out_rgb is NULL");
+    const size_t bytes = (size_t)m->prog_w * m->prog_h * 3 * sizeof(float);
+    return on_root(m, [&](Rank& r) {
+        RK_HIP(r, hipSetDevice(r.device));
+        RK_HIP(r, hipMemcpy(out_rgb, m->d_accum, bytes, hipMemcpyDeviceToHost));
+    });
+}
+
+int spt_multi_progressive_end(spt_multi* m)
+{
+    if (!m) return 1;
+    const int rc = on_root(m, [&](Rank& r) {
+        RK_HIP(r, hipSetDevice(r.device));
+        if (m->d_accum) RK_HIP(r, hipFree(m->d_accum));
+        m->d_accum = nullptr;
+    });
+    m->prog_w = m->prog_h = 0;
+    return rc;
 }
 
 }  // extern "C"

@@ -152,12 +152,30 @@ public:
         return out;
     }
     const spt_multi_stats& stats() const { return stats_; }
+    // the render thread's loop over all devices (smallpt.cpp:895-942; spt_multi_progressive_*): accumBuffer on the root device
+    void progressiveBegin(size_t imageWidth, size_t imageHeight)
+    {
+        check(spt_multi_progressive_begin(m_, (uint32_t)imageWidth, (uint32_t)imageHeight));
+        pw_ = imageWidth; ph_ = imageHeight;
+    }
+    void progressiveFrame(const spt_camera& camera, size_t sampleCountPerJitterCell, size_t seed, bool clear)
+    {
+        check(spt_multi_progressive_frame(m_, &camera, (uint32_t)sampleCountPerJitterCell, (uint64_t)seed, clear ? 1 : 0, &stats_));
+    }
+    std::vector<float3> progressiveSnapshot()
+    {
+        std::vector<float3> out(pw_ * ph_);
+        check(spt_multi_progressive_snapshot(m_, reinterpret_cast<float*>(out.data())));
+        return out;
+    }
+    void progressiveEnd() { check(spt_multi_progressive_end(m_)); }
 
 private:
     void check(int rc)
     {
         if (rc) throw std::runtime_error(spt_multi_last_error(m_));
     }
+    size_t pw_ = 0, ph_ = 0;
     spt_multi* m_ = nullptr;
     spt_multi_stats stats_{};
 };

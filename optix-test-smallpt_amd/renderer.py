@@ -325,6 +325,28 @@ class MultiRenderer:
     def framebuffer_ptr(self):
         return self._lib.spt_multi_framebuffer(self._h)
 
+    # the viewer's render loop over all devices (spt_multi_progressive_*): accumBuffer on the root device
+    def progressive_begin(self, w, h):
+        self._check(self._lib.spt_multi_progressive_begin(self._h, w, h))
+        self._prog = (w, h)
+
+    def progressive_frame(self, samps_per_cell, seed, clear=False, camera=None):
+        """outImage = render(camera, ..., seed) on all devices; accumBuffer = outImage (clear) or += outImage on the root."""
+        w, h = self._prog
+        cam = camera if camera is not None else pinhole_camera()
+        st = SptMultiStats()
+        self._check(self._lib.spt_multi_progressive_frame(self._h, C.byref(cam), samps_per_cell, seed, 1 if clear else 0, C.byref(st)))
+        return {"samples": int(st.samples), "bounces": int(st.bounces), "render_ms": float(st.render_ms), "gather_ms": float(st.gather_ms), "ndev": int(st.ndev)}
+
+    def progressive_snapshot(self):
+        w, h = self._prog
+        out = np.empty((h, w, 3), dtype=np.float32)
+        self._check(self._lib.spt_multi_progressive_snapshot(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def progressive_end(self):
+        self._check(self._lib.spt_multi_progressive_end(self._h))
+
 
 class ProgressiveRenderer:
     """The viewer's render-thread loop (smallpt.cpp:895-942) with the accumulation buffer resident in HBM:

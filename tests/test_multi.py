@@ -97,6 +97,31 @@ def test_several_ranks_on_one_device_assemble_the_same_image(pkg, renderer, rank
 
 
 @pytest.mark.gpu
+def test_multi_progressive_loop_accumulates_oracle_frames(pkg, oracle):
+    """The viewer's render loop through the multi-GPU front (spt_multi_progressive_*; three ranks share device 0): two frames,
+    a camera change -- the next frame replaces accumBuffer (smallpt.cpp:924-930) -- and two more; accumBuffer on the root equals
+    the sum of the oracle's frames, and the front refuses a frame before _begin."""
+    w, h, samps = 40, 27, 1
+    sc = pkg.cornell9()
+    cam, cam2 = pkg.pinhole_camera(), pkg.pinhole_camera(org=(0, -0.99, 0))
+    with pkg.MultiRenderer((0, 0, 0), copy_exchange=True) as m:
+        m.set_scene(sc)
+        with pytest.raises(pkg.SptError, match="progressive_begin"):
+            m._check(m._lib.spt_multi_progressive_snapshot(m._h, None))
+        m.progressive_begin(w, h)
+        for seed in (0, 1):
+            st = m.progressive_frame(samps, seed, clear=False, camera=cam)
+            assert st["ndev"] == 3 and st["samples"] == w * h * 4 * samps
+        acc = sum(oracle.render(sc, w, h, samps, seed=s, normalise=False, camera=cam)[0] for s in (0, 1))
+        assert np.array_equal(m.progressive_snapshot(), acc)
+        m.progressive_frame(samps, 2, clear=True, camera=cam2)
+        m.progressive_frame(samps, 1, clear=False, camera=cam2)
+        acc = oracle.render(sc, w, h, samps, seed=2, normalise=False, camera=cam2)[0] + oracle.render(sc, w, h, samps, seed=1, normalise=False, camera=cam2)[0]
+        assert np.array_equal(m.progressive_snapshot(), acc)
+        m.progressive_end()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["copy3", "self"])
 def test_failed_rank_returns_its_error_and_the_object_stays_usable(pkg, renderer, mode):
     """One rank's render is made to fail (kernel watchdog of its context at 0.1 us): spt_multi_render must return non-zero with
