@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <stdexcept>
@@ -82,6 +83,7 @@ struct spt_ctx {
     bool acc_recorded = false;
     bool frame_in_flight = false;  // a spt_progressive_frame_async of this lane has not been waited for
     uint32_t lanes_attached = 0;   // owner: lanes attached so far (spreads them over the stream priorities)
+    uint32_t frames_in_flight_hint = 1;   // set by spt_progressive_frame_async for its launch: lanes of the loop (sizes a short launch's grid)
     unsigned long long pool_stats[24] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
     float4* d_cells = nullptr;
@@ -899,6 +901,16 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         if (per_cu == 0) {
             const uint32_t by_lds = (uint32_t)((160u * 1024u) / lds);
             per_cu = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
+            // A short launch (the viewer's frames: 3.7 M samples = 900 per wave of a full grid) is over before the slot pools of four
+            // workgroups per CU ever run full: with half the waves the batches are fuller, and the other half of every CU's LDS is free
+            // for the next frame's kernel when several frames are in flight.  Measured at 1280x720 x 4 spp, frames/s with 4 / 2 / 1
+            // workgroups per CU (profiles/r03_small_launch_ab.txt): one frame at a time 427 / 450 / 411, two in flight 675 / 773 / 730,
+            // four 935 / 1155 / 1152, eight 1197 / 1575 / 1756; from 8 spp on (1024x768) a single launch is faster with four again.
+            // So: launches below 4 Mi samples take two, one when six or more frames are in flight (the lanes of
+            // spt_progressive_frame_async know their number).  SPT_SMALL_LAUNCH_BLOCKS overrides (experiments).
+            static const uint32_t forced = [] { const char* e = std::getenv("SPT_SMALL_LAUNCH_BLOCKS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+            const uint32_t small_blocks = forced ? forced : (c->frames_in_flight_hint >= 6u ? 1u : 2u);
+            if (npix * 4ull * samps < (4ull << 20) && per_cu > small_blocks) per_cu = small_blocks;
         }
         uint64_t blocks = (uint64_t)c->cu_count * per_cu;
         const uint64_t needed = (ntasks + 255) / 256;
@@ -1145,7 +1157,10 @@ int spt_progressive_frame_async(spt_ctx* c, spt_ctx* owner, const spt_camera* ca
         return c->fail("spt_progressive_frame_async: call spt_progressive_attach(lane, owner) first");
     if (c->frame_in_flight) return c->fail("spt_progressive_frame_async: the lane's previous frame has not been waited for");
     // :922 the frame is the UN-NORMALISED sum of Renderer::render, on the lane's stream
-    if (int rc = spt_render_rows_device(c, cam, c->prog_w, c->prog_h, 0, c->prog_h, samps, seed, 0u, c->d_frame, nullptr)) return rc;
+    c->frames_in_flight_hint = owner->lanes_attached + 1u;           // the owner and its lanes each keep a frame in flight
+    const int rrc = spt_render_rows_device(c, cam, c->prog_w, c->prog_h, 0, c->prog_h, samps, seed, 0u, c->d_frame, nullptr);
+    c->frames_in_flight_hint = 1u;
+    if (rrc) return rrc;
     // :927-937 accumBuffer (clear ? = : +=) outImage, behind the previous accumulation whichever lane issued it
     if (owner->acc_recorded) SPT_HIP(c, hipStreamWaitEvent(c->stream, owner->ev_acc, 0));
     SPT_HIP(c, spt_k_accumulate(owner->d_accum, c->d_frame, (size_t)c->prog_w * c->prog_h * 3, clear, c->stream));
