@@ -1198,7 +1198,7 @@ int spt_progressive_snapshot(spt_ctx* c, float* out_rgb)
     return 0;
 }
 
-// Diagnostic (tuning variant bit 8): per-phase wave-time sums [0..7], iterations, lane counts of the last launch.
+// Test hook (spt_internal.h): the chunk order the last pool launch left for the next launch of its view.
 int spt_chunk_order_snapshot(spt_ctx* c, uint32_t* order, uint32_t cap, uint32_t* nchunks)
 {
     if (!c || !nchunks) return 1;
@@ -1212,6 +1212,7 @@ int spt_chunk_order_snapshot(spt_ctx* c, uint32_t* order, uint32_t cap, uint32_t
     return 0;
 }
 
+// Diagnostic (tuning variant bit 8): per-phase wave-time sums [0..7], iterations, lane counts of the last launch.
 int spt_diag(spt_ctx* c, unsigned long long* out24)
 {
     if (!c || !out24) return 1;
