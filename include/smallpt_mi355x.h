@@ -166,6 +166,10 @@ int  spt_set_sphere_accel(spt_ctx* ctx, int accel);
 /* Vector<Hit> Intersector::traceRays(const PathContrib*, size_t) (smallpt.cpp:460-470, :553-587): closest hit of n rays
  * against the current mesh scene; host buffers in and out like the reference's RTP_BUFFER_TYPE_HOST queries (:571-575). */
 int  spt_trace_rays(spt_ctx* ctx, const spt_ray* rays, uint64_t n, spt_hit* hits);
+/* The same query on DEVICE buffers of this context's device (n spt_ray in, n spt_hit out; what OptiX Prime's RTP_BUFFER_TYPE_CUDA_LINEAR
+ * buffers are to the reference's intersector, smallpt.cpp:571-575): enqueued on `hip_stream` (NULL = the context's stream), returns
+ * without waiting.  No bytes cross the host link. */
+int  spt_trace_rays_device(spt_ctx* ctx, const void* d_rays, uint64_t n, void* d_hits, void* hip_stream);
 /* Host-only helper: makeSphereTriMesh(origin, radius, subdivLongitude) (scene.cpp:3-48): fills (L+1)(2L+1) positions and
  * normals and 4L^2 triangles (L = subdiv_longitude, default 32 at scene.h:17); returns the triangle count. */
 uint32_t spt_make_sphere_trimesh(const float origin[3], float radius, uint32_t subdiv_longitude,

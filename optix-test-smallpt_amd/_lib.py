@@ -49,6 +49,7 @@ SYMBOLS = {
     "spt_set_mesh_accel": (C.c_int, [_P, C.c_int]),
     "spt_set_sphere_accel": (C.c_int, [_P, C.c_int]),
     "spt_trace_rays": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "spt_trace_rays_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "spt_make_sphere_trimesh": (C.c_uint32, [C.c_float * 3, C.c_float, C.c_uint32, _P, _P, _P]),
     "spt_camera_smallpt": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(SptCamera)]),
     "spt_camera_pinhole": (C.c_int, [C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float, C.POINTER(SptCamera)]),

@@ -92,6 +92,12 @@ public:
         check(spt_trace_rays(ctx_, reinterpret_cast<const spt_ray*>(rays), (uint64_t)n, reinterpret_cast<spt_hit*>(hits.data())));
         return hits;
     }
+    // the same query on device buffers (n Ray in, n Hit out, this context's device), enqueued on `hipStream` (nullptr: the context's
+    // stream) without waiting: what RTP_BUFFER_TYPE_CUDA_LINEAR buffers are to the reference's Prime query (smallpt.cpp:571-575)
+    void traceRaysDevice(const void* dRays, size_t n, void* dHits, void* hipStream = nullptr)
+    {
+        check(spt_trace_rays_device(ctx_, dRays, (uint64_t)n, dHits, hipStream));
+    }
 
     const spt_stats& stats() const { return stats_; }
     spt_ctx* handle() { return ctx_; }

@@ -155,6 +155,18 @@ class Renderer:
         self._check(self._lib.spt_trace_rays(self._h, rays.ctypes.data_as(C.c_void_p), n, hits.ctypes.data_as(C.c_void_p)))
         return hits
 
+    def trace_rays_device(self, rays_t, hits_t=None, stream=None):
+        """spt_trace_rays_device: rays_t = contiguous float32 CUDA tensor (n, 6) on this renderer's device; returns the float32 tensor
+        (n, 11) of Hit records (dist, instId and triId as raw bits, x, n, uv), enqueued on `stream` (a torch stream; default: current)."""
+        import torch
+        assert rays_t.is_cuda and rays_t.dtype == torch.float32 and rays_t.is_contiguous() and rays_t.shape[-1] == 6
+        n = rays_t.numel() // 6
+        if hits_t is None:
+            hits_t = torch.empty((n, 11), dtype=torch.float32, device=rays_t.device)
+        st = (stream if stream is not None else torch.cuda.current_stream(rays_t.device)).cuda_stream
+        self._check(self._lib.spt_trace_rays_device(self._h, C.c_void_p(rays_t.data_ptr()), n, C.c_void_p(hits_t.data_ptr()), C.c_void_p(st)))
+        return hits_t
+
     def set_tuning(self, blocks_per_cu=0, variant=0):
         self._check(self._lib.spt_set_tuning(self._h, blocks_per_cu, variant))
         self._state["tuning"] = (int(blocks_per_cu), int(variant))

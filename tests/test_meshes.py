@@ -60,9 +60,24 @@ def test_trace_rays_matches_oracle(pkg, renderer, oracle):
     assert (got["dist"] < 1e20).sum() > n // 2 and len(set(got["instId"][got["dist"] < 1e20])) >= 4
     k = len(rays) - 4
     assert got[k]["dist"] == 2.0 and tuple(got[k]["uv"]) == (0.25, 0.5) and got[k]["instId"] == 5      # the KAT through the GPU
+    # the same query on device buffers (spt_trace_rays_device), on the caller's stream, in both closest-hit modes
+    import torch
+    rays_t = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
+    for accel in (pkg.ACCEL_EXHAUSTIVE, pkg.ACCEL_BVH):
+        renderer.set_mesh_accel(accel)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            hits_t = renderer.trace_rays_device(rays_t, stream=side)
+        side.synchronize()
+        assert hits_t.cpu().numpy().tobytes() == renderer.trace_rays(rays).tobytes()
+        if accel == pkg.ACCEL_EXHAUSTIVE:
+            assert hits_t.cpu().numpy().tobytes() == ref.tobytes()
+    renderer.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
     renderer.set_scene(pkg.cornell9())
     with pytest.raises(pkg.SptError, match="no mesh scene"):
         renderer.trace_rays(rays[:2])
+    with pytest.raises(pkg.SptError, match="no mesh scene"):
+        renderer.trace_rays_device(rays_t)
 
 
 @pytest.mark.gpu
