@@ -875,7 +875,8 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
     if (c->mesh_scene || sphere_bvh) {
         // (a short launch -- the viewer's frames -- takes three workgroups per CU instead of four: 661 -> 672 frames/s on the shipped scene
         // through the hierarchy at 1280x720 x 4 spp, 949 -> 1033 with two frames in flight, which then share the CUs; tools/ab_mesh_viewer_blocks.py)
-        const uint32_t mesh_per_cu = c->blocks_per_cu ? c->blocks_per_cu : (npix * 4ull * samps < (4ull << 20) ? 3u : 4u);
+        const bool through_hierarchy = sphere_bvh || (c->mesh_scene && c->accel == SPT_ACCEL_BVH && c->bvh_ready);   // (the exhaustive tile loop keeps four)
+        const uint32_t mesh_per_cu = c->blocks_per_cu ? c->blocks_per_cu : (through_hierarchy && npix * 4ull * samps < (4ull << 20) ? 3u : 4u);
         uint64_t blocks = (uint64_t)c->cu_count * mesh_per_cu;
         const uint64_t needed = (ntasks + 255) / 256;
         if (blocks > needed) blocks = needed;
