@@ -950,7 +950,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         P.slot_state = reinterpret_cast<uint2*>(c->d_stack + stack_floats);
         P.watchdog_ticks = c->watchdog_ticks;
         // Cost-ordered dispatch: the queue hands out chunks of 64 tasks; every launch records how long each chunk kept its wave
-        // busy, and a launch of the SAME view (scene, camera, image, band, samples -- the viewer's frames, a repeated render; the seed
+        // busy, and a launch of the SAME view (scene, camera, image, band, samples -- a repeated render, a progressive loop's next frame; the seed
         // may differ, a pixel's cost is a property of what it looks at) starts the expensive chunks first.  Results do not depend on
         // the dispatch order.  Tuning bit 13 switches it off for this kernel (A/B).
         const uint32_t nchunks = (uint32_t)((ntasks + 63) / 64);
