@@ -53,7 +53,7 @@ struct spt_ctx {
     float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
     size_t stack_cap = 0;          // in floats
     bool last_was_pool = false;
-    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy, 4 grid kernel
+    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy, 4 grid kernel (lanes own paths), 5 grid kernel with path pools
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
     float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
@@ -851,6 +851,47 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         P.stack = c->d_stack;
         P.watchdog_ticks = c->watchdog_ticks;
         const uint32_t lsel = (c->variant >> 16) & 0xFFu;
+        // ---- round 4: wave-private path pools with register-resident walkers (spt_gpool.hip) whenever the tables leave the LDS for
+        // them: R begun walks of 48 bytes + two byte lists per wave beside the grid tables.  Tuning bit 24 keeps the lane-owned kernel
+        // (A/B); SPT_GPOOL="S,R,drain,min_batch[,walk_iters]" overrides the pool geometry (experiments). ----
+        if (!(c->variant & 0x1000000u)) {
+            static const char* env = std::getenv("SPT_GPOOL");
+            uint32_t S = 192, Rwant = 96, drain = 24, minb = 32, witers = 4;
+            if (env) { unsigned a = 0, b2 = 0, d2 = 0, m2 = 0, w2 = 0; const int got = std::sscanf(env, "%u,%u,%u,%u,%u", &a, &b2, &d2, &m2, &w2); if (got >= 4) { S = a; Rwant = b2; drain = d2; minb = m2; } if (got == 5) witers = w2; }
+            const uint32_t waves = threads / 64u;
+            const size_t fixed = spt_gpool_lds_bytes(&c->grid, waves, S, 0);
+            const size_t room = fixed < (size_t)160 * 1024 ? (size_t)160 * 1024 - fixed : 0;
+            uint32_t R = (uint32_t)(room / ((size_t)waves * 56u)) & ~3u;
+            if (R > Rwant) R = Rwant & ~3u;
+            if (R >= 48u && c->n <= 0xFFFFu) {
+                const size_t stack_floats = spt_gpool_stack_floats(blocks, waves, S);
+                const size_t need = stack_floats + spt_gpool_slot_floats(blocks, waves, S);
+                if (need > c->stack_cap) {
+                    if (c->d_stack) (void)hipFree(c->d_stack);
+                    c->d_stack = nullptr; c->stack_cap = 0;
+                    SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_stack), need * sizeof(float)));
+                    c->stack_cap = need;
+                }
+                P.stack = c->d_stack;
+                spt::QParams Q{};
+                Q.slots = reinterpret_cast<float4*>(c->d_stack + stack_floats);
+                Q.S = S; Q.R = R; Q.drain = drain; Q.min_batch = minb; Q.walk_iters = witers ? witers : 1u;
+                SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
+                SPT_HIP(c, hipEventRecord(c->ev_start, st));
+                SPT_HIP(c, spt_gpool_launch(&P, &c->grid, c->d_grid_cells, c->d_grid_refs, c->d_grid_always, &Q, blocks, threads, (c->variant & 0x100u) ? 1 : 0, st));
+                SPT_HIP(c, hipEventRecord(c->ev_mid, st));
+                SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
+                SPT_HIP(c, hipEventRecord(c->ev_stop, st));
+                c->pending = true;
+                c->last_was_pool = false;
+                c->last_kernel = 5;
+                c->last = spt_stats{};
+                c->last.samples = npix * 4ull * samps;
+                c->last.grid_blocks = blocks;
+                c->last.block_threads = threads;
+                return 0;
+            }
+        }
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));
         SPT_HIP(c, spt_grid_launch(&P, &c->grid, c->d_grid_cells, c->d_grid_refs, c->d_grid_always, blocks, threads, lsel ? lsel - 1u : 16u, (c->variant & 0x100u) ? 1 : 0, st));
@@ -1063,7 +1104,7 @@ int spt_sync(spt_ctx* c, spt_stats* stats)
         c->last.max_depth_kills = ctr[1];
         if (c->variant & 0x100u) SPT_HIP(c, hipMemcpy(c->diag, c->d_counters + 2, sizeof c->diag, hipMemcpyDeviceToHost));
         c->pending = false;
-        if (c->last_was_pool || c->last_kernel == 4) {
+        if (c->last_was_pool || c->last_kernel == 4 || c->last_kernel == 5) {
             SPT_HIP(c, hipMemcpy(c->pool_stats, c->d_counters + 2, sizeof c->pool_stats, hipMemcpyDeviceToHost));
             if (c->pool_stats[6] != 0)
                 return c->fail("spt_sync: %llu waves hit the kernel watchdog; the image is incomplete", c->pool_stats[6]);
@@ -1237,7 +1278,7 @@ int spt_chunk_order_snapshot(spt_ctx* c, uint32_t* order, uint32_t cap, uint32_t
 int spt_diag(spt_ctx* c, unsigned long long* out24)
 {
     if (!c || !out24) return 1;
-    if (c->last_was_pool || c->last_kernel == 4) {
+    if (c->last_was_pool || c->last_kernel == 4 || c->last_kernel == 5) {
         std::memcpy(out24, c->pool_stats, sizeof c->pool_stats);
         return 0;
     }

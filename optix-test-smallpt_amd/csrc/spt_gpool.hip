@@ -1,0 +1,661 @@
+// spt_gpool.hip -- persistent path-tracing kernel for large sphere tables on gfx950 (MI355X), round 4: the uniform grid of spt_grid.h
+// (exhaustive-equivalent closest hit of intersectGlobalSpheres, smallpt.cpp:54-70 over scene.cpp:129-140) driven by wave-private
+// PATH POOLS instead of lanes that own their path (spt_grid.hip, which stays for tables that leave no LDS for the pools).
+//
+// Why: in spt_grid.hip a lane carries one path through regenerate -> begin -> walk -> shade, so at any moment about half the lanes
+// of a wave walk while the others wait to be shaded, and the walkers split between the TEST and the STEP body: 45 % lane
+// utilisation (profiles/r03_config5_pmc_summary.txt).  Here the three kinds of work run on different sets of lanes:
+//
+//   * every WAVE owns S path slots.  A slot is one task (one D9 block of a jitter cell, smallpt.cpp:299-309) with at most one path
+//     in flight, so emission events are accumulated in the order of D9.  A slot's state -- origin, direction, weight, RNG keys, depth,
+//     task, block sum: 96 bytes -- lives in GLOBAL memory (wave-private lines, L2 / Infinity-Cache resident); LDS holds the grid
+//     tables (one copy per CU, as in spt_grid.hip), per wave a stack of R begun walks (READY, 56 bytes each) and byte lists of slot ids.
+//   * the 64 lanes of the wave are WALKERS: a lane holds one walk in registers (ray, exit parameters, cell, nearest key) and runs
+//     the fused body { leave the cell if all its spheres are tested; test the next sphere } until its walk ends.  Finished lanes
+//     write (key, index) to their slot, queue it for shading by material class and take the next begun walk from READY, `drain`
+//     lanes at a time, so the walk loop runs with (almost) every lane walking -- whatever the shading side is doing.
+//   * shading runs in BATCHES of up to 64 slots of one class with every lane active, as in spt_pool.hip: HIT (DIFF / SPEC,
+//     smallpt.cpp:208-223), HITR (glass, :225-263), GEN (next camera sample / pending transmitted child / new task,
+//     :304-340, :252).  The batch's lanes then BEGIN the new ray -- ray test, always-tested spheres (the walls and the light of a
+//     Cornell box), walk set-up (spt_grid.h) -- and push it onto READY.
+//
+// RNG (D7), summation order (D9), sin/cos (D17), depth cap (D18), zero-weight cut (D19) and every arithmetic expression are those
+// of spt_grid.hip / spt_pool.hip / the oracle: results are bit-identical, bounce counts included.
+#include "spt_device.h"
+#define SPT_GRID_DEVICE_ONLY
+#include "spt_grid.h"
+#include "spt_kernel.h"
+
+namespace spt {
+
+constexpr int kQBlock = 1024;                                    // threads per workgroup (one workgroup per CU shares the LDS tables)
+constexpr uint32_t kQEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) + 1
+constexpr uint32_t kQInfKey = 0x60AD78ECu - kQEpsBias;           // key of 1e20f (maths.h:16)
+constexpr int kQSlotF4 = 6;                                      // float4 per slot in global memory
+constexpr int kQStackF4 = 4;                                     // one pending child = one 64-byte line
+
+__device__ __forceinline__ uint32_t lane_id_q() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t rank_q(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t uniq(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// intersectAnalytic of one sphere record {c, r*r} on integer keys (scene.cpp:129-140, smallpt.cpp:59-65), as in spt_grid.hip
+__device__ __forceinline__ uint32_t sphere_key_q(const float4 g, f3 o, f3 d)
+{
+    const f3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);                                  // :132
+    const float bb = dot(op, d);                                                        // :133
+    const float det = bb * bb - dot(op, op) + g.w;                                      // :133 (g.w = r*r)
+    const float sd = sqrt_rsq(det);                                                     // :134
+    const uint32_t key1 = __float_as_uint(bb - sd) - kQEpsBias;                         // :135
+    const uint32_t key2 = __float_as_uint(bb + sd) - kQEpsBias;
+    return key1 < key2 ? key1 : key2;
+}
+
+// packed word of a slot (Q1.w): [11:0] depth, [14:12] branch bits (D7), [15] weight-may-be-non-finite flag, [31:30] pending
+// transmitted children of the slot's current sample
+__device__ __forceinline__ uint32_t pack_q(uint32_t depth, uint32_t branchf, uint32_t sp) { return depth | (branchf << 12) | (sp << 30); }
+
+enum { QC_GEN = 0, QC_HIT = 1, QC_HITR = 2 };
+
+// Global slot record (6 float4): Q0 {o.xyz, t_ok}  Q1 {d.xyz, packed}  Q2 {w.xyz, k1}  Q3 {rbase, task + 1, next sample, -}
+//                                Q4 {near key, near index, -, -}  Q5 {block sum xyz, -}
+template <bool STATS>
+__global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
+                                                       const uint16_t* __restrict__ g_refs, const uint32_t* __restrict__ g_always, const QParams Q)
+{
+    extern __shared__ float4 s_geom[];                           // n sphere records, then the grid tables, then the wave regions
+    const uint32_t ngeom = G.n ? G.n : 1u;
+    // cell headers of 8 bytes: {first reference << 13 | count (kGridBorder on the border), reference 0 | reference 1 << 16} -- the
+    // first two spheres of a cell are known as soon as its header is, without the round trip through the reference list
+    uint32_t* const s_cellh = reinterpret_cast<uint32_t*>(s_geom + ngeom);      // (two arrays: two independent 4-byte reads, no register pair)
+    uint32_t* const s_cellr = s_cellh + G.ncells;
+    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_cellr + G.ncells);   // nrefs cell references, then the always-tested list, one spare
+    // materials: {color.xyz, Refl_t | emissive << 2} per sphere (16 of the host table's 48 bytes: pmax = fmaxf(color) and color * (1 / pmax)
+    // are single IEEE operations that the shading batch repeats bit for bit; emission is read from global memory for emissive spheres only)
+    const uint32_t tables_bytes = (ngeom * 16u + G.ncells * 8u + ((G.nrefs + G.nalways + 2u) >> 1) * 4u + 15u) & ~15u;
+    float4* const s_mat = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_geom) + tables_bytes);
+    for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) {
+        s_geom[i] = K.geom[i];
+        const float4 mc = K.mat[3 * i + 1];
+        s_mat[i] = make_float4(mc.x, mc.y, mc.z, K.mat[3 * i].w);
+    }
+    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) {
+        const uint32_t h = g_cells[i];
+        uint32_t r01 = 0u;
+        if (h != kGridBorder) {
+            const uint32_t first = h >> kGridCountBits, cnt = h & ((1u << kGridCountBits) - 1u);
+            if (cnt > 0u) r01 = g_refs[first];
+            if (cnt > 1u) r01 |= (uint32_t)g_refs[first + 1u] << 16;
+        }
+        s_cellh[i] = h; s_cellr[i] = r01;
+    }
+    for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_refs[i] = g_refs[i];
+    for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
+
+    const uint32_t lane = lane_id_q();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t S = Q.S, R = Q.R;
+    const uint32_t wave_bytes = R * 56u + 2u * S;
+    float4* const RD0 = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_geom) + tables_bytes + ngeom * 16u + wave * wave_bytes);   // {o.xyz, near key}
+    float4* const RD1 = RD0 + R;                                 // {d.xyz, near index | slot << 16}
+    float4* const RD2 = RD1 + R;                                 // {tx, ty, tz, cell index}
+    uint2* const RD3 = reinterpret_cast<uint2*>(RD2 + R);        // header of the walk's start cell
+    uint8_t* const LH = reinterpret_cast<uint8_t*>(RD3 + R);     // S bytes: HIT list from index 0 up, HITR list from S - 1 down
+    uint8_t* const LGN = LH + S;                                 // S bytes: GEN list
+    const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave;
+    float4* const slots = Q.slots + (size_t)wave_gid * S * kQSlotF4;
+    float4* const gstack = reinterpret_cast<float4*>(K.stack) + (size_t)wave_gid * S * (3 * kQStackF4);
+    auto stack_rec = [&](uint32_t e, uint32_t slot) -> float4* { return gstack + (slot * 3u + e) * kQStackF4; };
+
+    // every slot starts on the GEN list as a finished, task-less slot
+    for (uint32_t s = lane; s < S; s += 64u) {
+        LGN[s] = (uint8_t)s;
+        slots[s * kQSlotF4 + 1] = make_float4(0.f, 0.f, 1.f, __uint_as_float(0u));
+        slots[s * kQSlotF4 + 3] = make_float4(0.f, __uint_as_float(0u), __uint_as_float(0u), 0.f);
+    }
+    __syncthreads();
+
+    // ---- wave-uniform state ----
+    uint32_t nR = 0, nH = 0, nHR = 0, nG = S;                    // READY records, HIT / HITR / GEN list lengths
+    uint32_t chunk_next = 0, chunk_end = 0;                      // this wave's private range of task ids
+    bool queue_empty = false;
+    unsigned long long nbounce = 0;
+    uint32_t nkill = 0;                                          // per lane
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    bool timed_out = false;
+    uint32_t n_loop = 0;
+    // statistics (STATS build)
+    unsigned long long st_iter = 0, st_act = 0, st_exch = 0, st_fin = 0, st_test = 0, st_step = 0, st_redo = 0;
+    unsigned long long st_bat[3] = {0, 0, 0}, st_lan[3] = {0, 0, 0};
+    unsigned long long t_dry = 0;                                // when this wave found the task queue empty
+    unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = 0;           // wave time: walk, exchange, generation batches, shading batches
+#define QSTAMP(i) if (STATS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
+
+    // ---- the lane's walk (registers).  wj <= wcnt: walking in a cell of wcnt references of which wj are tested (wj == wcnt: the cell is
+    // exhausted, the lane steps); wj > wcnt (1, 0): the lane holds no walk.  wfin != 0: the lane's walk has ended and waits for the
+    // exchange.  The walk runs one cell AHEAD of the tests: (wtx, wty, wtz, wci) belong to the cell after the current one, nh is that
+    // cell's header -- in flight while the current cell's spheres are tested -- and mex the parameter at which the ray leaves the
+    // current cell (what the stop rule of spt_grid.h (3) compares with the nearest hit).  The arithmetic and its order are those of
+    // grid_walk_exit / grid_walk_step, evaluated one cell early. ----
+    uint32_t wfin = 0;
+    f3 wo = mk(0, 0, 0), wd = mk(0, 0, 1);
+    float wtx = 0.f, wty = 0.f, wtz = 0.f, wdx = 0.f, wdy = 0.f, wdz = 0.f, mex = 0.f;
+    int32_t wsx = 0, wsy = 0, wsz = 0;
+    uint32_t wci = 0, wj = 1, wcnt = 0, wfirst = 0, wr01 = 0, nref = 0, near_key = kQInfKey, near_i = 0, wslot = 0;
+    uint32_t nhx = kGridBorder, nhy = 0u;
+
+    // the grid constants a walker lane needs when it takes a begun walk over: in VECTOR registers (in scalar ones they push the
+    // loop's masks into spill lanes; re-read from the kernel-argument segment they put a scalar-memory wait into every exchange)
+    float cellx = G.cell[0], celly = G.cell[1], cellz = G.cell[2];
+    int32_t stride_y = G.stride_y, stride_z = G.stride_z;
+    asm volatile("" : "+v"(cellx), "+v"(celly), "+v"(cellz), "+v"(stride_y), "+v"(stride_z));
+
+    if (STATS) ph_t = __builtin_amdgcn_s_memtime();
+    for (;;) {
+        if ((++n_loop & 63u) == 0u && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
+        uint32_t nAct = (uint32_t)__popcll(__ballot(wj <= wcnt));
+        uint32_t nFin = (uint32_t)__popcll(__ballot(wfin != 0u));
+        const uint32_t nEmp = 64u - nAct - nFin;
+        bool idle = true;                                        // nothing was done in this round: the wave's tasks are finished
+
+        if ((nFin != 0u && (nFin >= Q.drain || nAct == 0u)) || (nR != 0u && nEmp + nFin != 0u && (nEmp + nFin >= Q.drain || nAct == 0u))) {
+            // =============== exchange: finished walkers hand their hits over, empty lanes take begun walks ===============
+            if (STATS) { ++st_exch; st_fin += nFin; }
+            idle = false;
+            // (finished lanes are empty lanes already -- cur > end --, so the begun walks can be fetched before the hits are handed over:
+            // the LDS reads of both halves are in flight together)
+            const unsigned long long me = __ballot(wj > wcnt);
+            const uint32_t ne = (uint32_t)__popcll(me);
+            const uint32_t k = ne < nR ? ne : nR;
+            const uint32_t rk = rank_q(me);
+            const bool take = wj > wcnt && rk < k;
+            const uint32_t pos = take ? nR - 1u - rk : 0u;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+            uint2 h0 = make_uint2(0u, 0u);
+            if (take) { r0 = RD0[pos]; r1 = RD1[pos]; r2 = RD2[pos]; h0 = RD3[pos]; }
+            uint32_t hcls = 0u;                                  // 1: onto HIT, 2: onto HITR
+            if (wfin != 0u) {
+                reinterpret_cast<uint2*>(slots + wslot * kQSlotF4 + 4)[0] = make_uint2(near_key, near_i);
+                hcls = (near_key != kQInfKey && (__float_as_uint(s_mat[near_i].w) & 3u) == 2u) ? 2u : 1u;
+            }
+            const unsigned long long mh = __ballot(hcls == 1u), mr = __ballot(hcls == 2u);
+            if (hcls != 0u) LH[hcls == 2u ? S - 1u - nHR - rank_q(mr) : nH + rank_q(mh)] = (uint8_t)wslot;
+            nH += (uint32_t)__popcll(mh); nHR += (uint32_t)__popcll(mr);
+            wfin = 0u;
+            if (take) {
+                wo = mk(r0.x, r0.y, r0.z); near_key = __float_as_uint(r0.w);
+                wd = mk(r1.x, r1.y, r1.z);
+                const uint32_t pk = __float_as_uint(r1.w);
+                near_i = pk & 0xFFFFu; wslot = pk >> 16;
+                wtx = r2.x; wty = r2.y; wtz = r2.z; wci = __float_as_uint(r2.w);
+                // the walk's constants from the direction (spt_grid.h grid_axis_rate: what grid_walk_begin computed)
+                float iv; bool mv, ngx, ngy, ngz;
+                grid_axis_rate(wd.x, cellx, iv, mv, wdx, ngx);
+                grid_axis_rate(wd.y, celly, iv, mv, wdy, ngy);
+                grid_axis_rate(wd.z, cellz, iv, mv, wdz, ngz);
+                wsx = ngx ? -1 : 1; wsy = ngy ? -stride_y : stride_y; wsz = ngz ? -stride_z : stride_z;
+                wfirst = h0.x >> kGridCountBits; wcnt = h0.x & ((1u << kGridCountBits) - 1u); wj = 0u; wr01 = h0.y;   // the start cell (never a border cell)
+                mex = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));                   // grid_walk_exit of the start cell
+                grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, mex);  // one cell ahead
+                nhx = s_cellh[wci]; nhy = s_cellr[wci];
+            }
+            nR -= k;
+            nAct += k; nFin = 0u;
+            QSTAMP(1)
+        }
+
+        const uint32_t nFree = R - nR;
+        const bool starving = nR < Q.drain && nAct + Q.drain <= 64u;
+        const uint32_t aH = nH < nFree ? nH : nFree, aHR = nHR < nFree ? nHR : nFree, aG = nG < nFree ? nG : nFree;
+        uint32_t cls = QC_HITR, amax = aHR;
+        if (aH > amax) { cls = QC_HIT; amax = aH; }
+        if (aG > amax) { cls = QC_GEN; amax = aG; }
+        const uint32_t cap = amax < 64u ? amax : 64u;            // lanes of the largest batch available
+        const uint32_t minb = Q.min_batch < 64u ? Q.min_batch : 64u;
+
+        // =============== a batch of up to 64 slots of one class: pop the slots and issue the loads of their state; the walk below runs
+        // while they are in flight, the batch's code after it ===============
+        const bool run_batch = cap != 0u && (cap >= (starving ? minb : 64u) || nAct == 0u);
+        const uint32_t b = run_batch ? cap : 0u;
+        const bool valid = lane < b;
+        uint32_t slot = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, __builtin_inff()), q1 = make_float4(0.f, 0.f, 1.f, 0.f), q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 q4 = make_uint2(kQInfKey, 0u);
+        if (run_batch) {
+            idle = false;
+            if (cls == QC_GEN) { nG -= b; if (valid) slot = LGN[nG + lane]; }
+            else if (cls == QC_HIT) { nH -= b; if (valid) slot = LH[nH + lane]; }
+            else { if (valid) slot = LH[S - nHR + lane]; nHR -= b; }
+            if (STATS) { ++st_bat[cls]; st_lan[cls] += b; }
+            const float4* const lq = slots + slot * kQSlotF4;
+            // (every lane loads -- idle lanes read slot 0, never use it --: a merge with default values would need the data at once;
+            // and every class loads the five rows (a GEN batch needs two of them): a merge at a branch would, too)
+            q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q4 = reinterpret_cast<const uint2*>(lq + 4)[0];
+            { const float* const l3 = reinterpret_cast<const float*>(lq + 3); q3.x = l3[0]; q3.y = l3[1]; q3.z = l3[2]; }   // (a register loaded and never read would be reused by the walk: a wait)
+        }
+
+        if (nAct != 0u) {
+            // =============== walk: the fused STEP + TEST body until only `thr` lanes are left walking ===============
+            // (the walk stops for an exchange -- `drain` lanes finished, or that many free for the begun walks that wait -- or for a
+            // batch that is worth running once the walkers starve; all of these are "at most thr lanes still walk".  With a batch
+            // pending it lasts a few iterations only: as long as the batch's loads are in flight.)
+            idle = false;
+            uint32_t thr = 0u;
+            if (nAct + nFin > Q.drain) thr = nAct + nFin - Q.drain;           // finished lanes' = nFin + (nAct - act) >= drain
+            if ((nR != 0u || (cap >= minb && nR < Q.drain)) && 64u - Q.drain > thr) thr = 64u - Q.drain;
+            uint32_t iters = run_batch ? Q.walk_iters : 0xFFFFFFFFu;
+            for (;;) {
+                if (STATS) { ++st_iter; st_act += (uint32_t)__popcll(__ballot(wj <= wcnt)); }
+                // The LDS reads of an iteration are issued by EVERY lane, outside the exec-masked blocks (lanes that do not need them
+                // re-read what they hold, idle lanes read valid stale addresses): their number per iteration is then fixed, the
+                // compiler waits with counted lgkmcnt(N), and only the sphere record's round trip is exposed -- the header of the next
+                // cell and the reference after next arrive while the test's arithmetic runs.
+                if (wj == wcnt) {
+                    // ---- STEP: all spheres of the cell are tested; leave it (spt_grid.h (3)) ----
+                    const float near_t = __uint_as_float(near_key + kQEpsBias);    // 1e20 while nothing is hit
+                    if (mex < near_t && nhx != kGridBorder) {    // else: every cell up to the hit has been visited, or the ray has left the table
+                        wfirst = nhx >> kGridCountBits; wcnt = nhx & ((1u << kGridCountBits) - 1u); wj = 0u; wr01 = nhy;
+                        mex = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));           // grid_walk_exit of the cell just entered
+                        grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, mex);
+                    } else {
+                        wj = 1u; wcnt = 0u; wfin = 1u;
+                    }
+                    if (STATS) st_step += 1;                     // (per lane; reduced at the end)
+                }
+                nhx = s_cellh[wci]; nhy = s_cellr[wci];          // header of the cell after the current one (consumed by the lane's next STEP)
+                // the next sphere of the lane's cell: the first two come with the header, the others from the list one iteration ahead
+                const uint32_t ti = wj == 0u ? (wr01 & 0xFFFFu) : (wj == 1u ? wr01 >> 16 : nref);
+                const float4 tg = s_geom[ti];
+                const bool testing = wj < wcnt;
+                wj += testing ? 1u : 0u;
+                nref = s_refs[wfirst + wj];                      // (wj <= wcnt: inside the list or its spare entry)
+                if (testing) {
+                    // ---- TEST ----
+                    const uint32_t key = sphere_key_q(tg, wo, wd);
+                    // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
+                    const bool better = (key < near_key) | ((key == near_key) & (ti < near_i));
+                    near_key = better ? key : near_key;
+                    near_i = better ? ti : near_i;
+                    if (STATS) st_test += 1;
+                }
+                if ((uint32_t)__popcll(__ballot(wj <= wcnt)) <= thr || --iters == 0u) break;
+            }
+            QSTAMP(0)
+        }
+
+        if (run_batch) {
+        float4* const sq = slots + slot * kQSlotF4;
+        // per-lane path registers handed from the class code to the begin of the new ray
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), w = mk(0, 0, 0);
+        uint32_t depth = 0, branchf = 0, rbase = 0, k1 = 0, sp = 0;
+        bool has_ray = false;
+        bool to_gen = false;                                     // the slot's path ended: back onto the GEN list
+        uint32_t requeue = 0;                                    // 1 / 2: the redo found a hit of the other class: onto HIT / HITR with the new answer
+
+        if (cls == QC_GEN) {
+            // ================= GEN: continue the slot's task (smallpt.cpp:304-340, :252 pop) =================
+            sp = __float_as_uint(q1.w) >> 30;
+            uint32_t task1 = __float_as_uint(q3.y), snext = __float_as_uint(q3.z);     // task + 1 (0: the slot has no task)
+            uint32_t send = 0;
+            if (task1 != 0u) {
+                const uint32_t sbeg = ((task1 - 1u) & ((1u << K.nb_log2) - 1u)) * K.sb;
+                send = sbeg + K.sb < K.samps ? sbeg + K.sb : K.samps;
+            }
+            bool gen = false, need_task = false;
+            if (valid) {
+                if (sp > 0u) {                                   // pending transmitted child (the reflected subtree is done)
+                    --sp;
+                    const float4* rec = stack_rec(sp, slot);
+                    const float4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
+                    o = mk(s0.x, s0.y, s0.z); d = mk(s1.x, s1.y, s1.z); w = mk(s2.x, s2.y, s2.z);
+                    const uint32_t db = __float_as_uint(s0.w);
+                    depth = db & 0xFFFu; branchf = db >> 16;
+                    const uint32_t k0 = __float_as_uint(s1.w);
+                    k1 = __float_as_uint(s2.w);
+                    rbase = rng_base(k0, branchf & 7u, depth);
+                    has_ray = true;
+                } else if (snext == send) {
+                    need_task = true;                            // sample block finished (or the slot never had a task)
+                } else {
+                    gen = true;
+                }
+            }
+            const unsigned long long need_mask = __ballot(need_task);
+            if (need_mask != 0ull) {
+                if (need_task && task1 != 0u) { const float4 a = sq[5]; K.cells[task1 - 1u] = make_float4(a.x, a.y, a.z, 0.0f); }
+                // wave-private chunks of task ids; only the refill touches the global queue word
+                const uint32_t cntn = (uint32_t)__popcll(need_mask);
+                const uint32_t rk = rank_q(need_mask);
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t base_old = chunk_next;
+                uint32_t base_new = 0;
+                if (cntn > avail) {
+                    if (!queue_empty) {
+                        const int leader = __ffsll((long long)need_mask) - 1;
+                        uint32_t nb = 0;
+                        if ((int)lane == leader) nb = atomicAdd(K.queue, 64u);
+                        base_new = uniq(__shfl(nb, leader));
+                        if (base_new >= K.ntasks) { queue_empty = true; if (STATS) t_dry = __builtin_amdgcn_s_memtime(); }
+                    } else {
+                        base_new = K.ntasks;                     // nothing left: ids >= ntasks mean "no task"
+                    }
+                    chunk_next = base_new + (cntn - avail);
+                    chunk_end = base_new + 64u;
+                    if (queue_empty) { chunk_next = chunk_end = 0; }
+                } else {
+                    chunk_next += cntn;
+                }
+                if (need_task) {
+                    const uint32_t nt = rk < avail ? base_old + rk : base_new + (rk - avail);
+                    if (nt < K.ntasks) {
+                        task1 = nt + 1u; gen = true;
+                        snext = (nt & ((1u << K.nb_log2) - 1u)) * K.sb;
+                        sq[5] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }                                            // else the slot retires: it is pushed onto no list
+                }
+            }
+            if (gen) {
+                // ---- camera ray of sample `snext` of the cell (smallpt.cpp:325-340 / :745-760), as in spt_grid.hip ----
+                typedef const __attribute__((address_space(4))) KParams* KArgs;        // K is the first kernel argument
+                KArgs kc = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kc));
+                const f3 cam_o = mk(kc->cam_o[0], kc->cam_o[1], kc->cam_o[2]);
+                const f3 cam_d = mk(kc->cam_d[0], kc->cam_d[1], kc->cam_d[2]);
+                const f3 cam_cx = mk(kc->cam_cx[0], kc->cam_cx[1], kc->cam_cx[2]);
+                const f3 cam_cy = mk(kc->cam_cy[0], kc->cam_cy[1], kc->cam_cy[2]);
+                const uint32_t task = task1 - 1u;
+                const uint32_t cellid = task >> K.nb_log2;
+                const uint32_t pix_local = cellid >> 2, cell = cellid & 3u;
+                const uint32_t ry = pix_local / K.w;
+                const uint32_t px = pix_local - ry * K.w;
+                const uint32_t py = K.row_begin + (ry >> K.rb_log2) * K.rb_stride + (ry & K.rb_mask);   // band or interleaved row blocks
+                const uint32_t pixel_idx = py * K.w + px;                    // GLOBAL index (:298)
+                const uint32_t p0 = mix32(pixel_idx + K.s0);
+                const uint32_t p1 = mix32(pixel_idx ^ K.s1);
+                const uint32_t index_in_pixel = cell * K.samps + snext;      // :306
+                const uint32_t k0 = mix32(p0 ^ (index_in_pixel * kGolden));
+                k1 = mix32(p1 + index_in_pixel * 0x85EBCA6Bu);
+                const float u1 = rng_draw(k0 + ((1u << 28) | 0u) * kGolden, k1);
+                const float u2 = rng_draw(k0 + ((1u << 28) | 1u) * kGolden, k1);
+                const uint32_t sx = cell & 1u, sy = cell >> 1;
+                float ax, ay;
+                if (kc->sampler == 0u) {
+                    const float r1 = 2 * u1;                                  // tent filter :327-330
+                    const float q1s = sqrt_rsq(r1 < 1 ? r1 : 2 - r1);
+                    const float dx = r1 < 1 ? q1s - 1 : 1 - q1s;
+                    const float r2 = 2 * u2;
+                    const float q2s = sqrt_rsq(r2 < 1 ? r2 : 2 - r2);
+                    const float dy = r2 < 1 ? q2s - 1 : 1 - q2s;
+                    // :331-332 in double like the reference; a / w as the exact Markstein sequence (tools/verify_exact_math.c)
+                    const double tx = ((double)sx + .5 + (double)dx) / 2.0 + (double)px;
+                    const double ty = ((double)sy + .5 + (double)dy) / 2.0 + (double)py;
+                    const double qx0 = tx * kc->inv_w, qy0 = ty * kc->inv_h;
+                    const double qx = __builtin_fma(__builtin_fma(-qx0, (double)kc->w, tx), kc->inv_w, qx0);
+                    const double qy = __builtin_fma(__builtin_fma(-qy0, (double)kc->h, ty), kc->inv_h, qy0);
+                    ax = (float)(qx - .5); ay = (float)(qy - .5);
+                } else {
+                    const float jx = ((float)sx + u1) * 0.5f, jy = ((float)sy + u2) * 0.5f;      // :750
+                    const float fx = 0.5f * (2 * jx - 1), fy = 0.5f * (2 * jy - 1);              // :753-758
+                    const float nx = (((float)px + 0.5f) + fx) * kc->inv_wf;                     // :628-631
+                    const float ny = (((float)py + 0.5f) + fy) * kc->inv_hf;
+                    ax = 2.f * nx - 1.f; ay = 2.f * ny - 1.f;                                    // :633
+                }
+                const f3 dd = cam_cx * ax + cam_cy * ay + cam_d;
+                const float inv = rcp_exact(sqrt_exact(dot(dd, dd)));
+                o = cam_o + dd * kc->cam_push;                                                  // :333
+                d = dd * inv;                                                                   // normalize(d)
+                w = mk(1, 1, 1); depth = 0; branchf = 0; rbase = k0;                             // :338-339
+                ++snext;
+                has_ray = true;
+            }
+            if (has_ray) {
+                sq[2] = make_float4(w.x, w.y, w.z, __uint_as_float(k1));
+                sq[3] = make_float4(__uint_as_float(rbase), __uint_as_float(task1), __uint_as_float(snext), 0.f);
+            }
+            QSTAMP(2)
+        } else {
+            // ================= HIT / HITR: shade the slot's closest hit (smallpt.cpp:168-263 under D2-D6, D18, D19) =================
+            const f3 ro = mk(q0.x, q0.y, q0.z), din = mk(q1.x, q1.y, q1.z);
+            w = mk(q2.x, q2.y, q2.z); k1 = __float_as_uint(q2.w);
+            rbase = __float_as_uint(q3.x);
+            const uint32_t pk = __float_as_uint(q1.w);
+            depth = pk & 0xFFFu; branchf = (pk >> 12) & 0xFu; sp = pk >> 30;
+            uint32_t hkey = q4.x, inst = q4.y;
+            // A walk's answer (hit or miss) stands only inside the ray's valid range (spt_grid.h (1): a direction whose length has drifted
+            // over a chain of mirror bounces is valid up to t_ok only): otherwise the exhaustive loop of smallpt.cpp:54-70 answers.
+            const bool redo = valid && __uint_as_float(hkey + kQEpsBias) > q0.w;
+            const unsigned long long mredo = __ballot(redo);
+            if (mredo != 0ull) {
+                if (STATS) st_redo += (unsigned long long)__popcll(mredo);
+                if (redo) { hkey = kQInfKey; inst = 0u; }
+                for (uint32_t i = 0; i < G.n; ++i) {
+                    const float4 g = s_geom[i];
+                    if (redo) {
+                        const uint32_t key = sphere_key_q(g, ro, din);
+                        if (key < hkey) { hkey = key; inst = i; }
+                    }
+                }
+                if (redo && hkey != kQInfKey) {
+                    const bool is_r = (__float_as_uint(s_mat[inst].w) & 3u) == 2u;
+                    if (is_r != (cls == QC_HITR)) requeue = is_r ? 2u : 1u;
+                }
+                if (requeue != 0u) {                             // the other class's batch shades it: the answer is final (t_ok = inf)
+                    sq[0] = make_float4(q0.x, q0.y, q0.z, __builtin_inff());
+                    reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(hkey, inst);
+                }
+            }
+            const bool live = valid && requeue == 0u;
+            if (live) to_gen = true;                             // unless the path goes on (below)
+            if (live && hkey != kQInfKey) {                                                 // else :168 miss (D13)
+                const float t = __uint_as_float(hkey + kQEpsBias);
+                const float4 gh = s_geom[inst];
+                const float4 mc = s_mat[inst];                                              // color.xyz, refl | emissive << 2
+                const uint32_t rb = __float_as_uint(mc.w);
+                const float pmax = __builtin_fmaxf(__builtin_fmaxf(mc.x, mc.y), mc.z);      // :177 (the host table's mat[3 i + 1].w)
+                const f3 hx = ro + din * t;                                                 // scene.cpp:137
+                const f3 n = normalize<false>(mk(hx.x - gh.x, hx.y - gh.y, hx.z - gh.z));   // scene.cpp:124
+                const f3 nl = dot(n, din) < 0 ? n : neg(n);                                 // :174 (D2)
+                f3 f = mk(mc.x, mc.y, mc.z);                                                // :175
+                if ((rb & 4u) != 0u || (branchf & 8u) != 0u) {                              // :179 (D4); + w*0 is skipped, exact for finite w
+                    const float4 a = sq[5], me = K.mat[3 * inst + 0];
+                    sq[5] = make_float4(a.x + w.x * me.x, a.y + w.y * me.y, a.z + w.z * me.z, 0.f);
+                }
+                bool cont = true;
+                if (depth > 5u) {                                                           // :188 (D5)
+                    if (rng_draw(rbase, k1) < pmax) f = f * rcp_exact<true>(pmax);          // :192 color * (1 / pmax): the host table's third row
+                    else cont = false;                                                      // :196
+                }
+                if (cont) {
+                    const f3 off = nl * 0.02f;                                              // :172 (D3)
+                    f3 no = hx + off, nd, nf = f;
+                    if (cls == QC_HIT) {
+                        if ((rb & 3u) == 0u) {                                              // DIFF :208-215
+                            const uint32_t u1bits = rng_draw_bits(rbase + kGolden, k1);
+                            const float r2 = rng_draw(rbase + 2u * kGolden, k1);
+                            const float r2s = sqrt_rsq(r2);
+                            float sn, cs;
+                            sincos2pi_bits(u1bits, sn, cs);                                  // D17
+                            const f3 ww = nl;
+                            const bool ay = __builtin_fabsf(ww.x) >= 0.1f;                  // (double)fabs(w.x) > .1, :211
+                            const f3 ur = mk(ay ? ww.z : 0.f, ay ? 0.f : -ww.z, ay ? -ww.x : ww.y);
+                            const float s2 = ay ? ww.x : ww.y;
+                            const float qu = ww.z * ww.z + s2 * s2;                          // dot(ur, ur) with the zero term dropped
+                            const f3 uu = ur * rcp_exact<false>(sqrt_rsq<true, true>(qu));
+                            const f3 vv = cross(ww, uu);
+                            nd = normalize<false>(uu * cs * r2s + vv * sn * r2s + ww * sqrt_rsq<true, true>(1 - r2));   // :212
+                        } else {
+                            nd = din - n * 2.0f * dot(n, din);                              // SPEC :218-223
+                        }
+                    } else {
+                        nd = din - n * 2.0f * dot(n, din);                                  // :218 reflRay
+                        const bool into = dot(n, nl) > 0;                                   // :225
+                        const float nnt = into ? 1.0f / 1.5f : 1.5f / 1.0f;                 // :228
+                        const float ddn = dot(din, nl);                                     // :229
+                        const float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);                // :230
+                        if (!(cos2t < 0)) {                                                 // else TIR :232-236
+                            const f3 tdir = normalize<true>(din * nnt - n * ((into ? 1.0f : -1.0f) * (ddn * nnt + sqrt_exact(cos2t))));   // :238
+                            const float R0 = (0.5f * 0.5f) / (2.5f * 2.5f);                 // :240-242
+                            const float cc = 1 - (into ? -ddn : dot(tdir, n));              // :243
+                            const float c2 = cc * cc;                                       // :244
+                            const float Re = R0 + (1 - R0) * c2 * c2 * cc;                  // :245
+                            const float Tr = 1 - Re;                                        // :246
+                            const f3 xin = hx - off;                                        // D3
+                            if (depth <= 2u) {                                              // :248 split (D6)
+                                const f3 tw = w * (f * Tr);
+                                if (!(tw.x == 0.f && tw.y == 0.f && tw.z == 0.f)) {
+                                    const uint32_t br = branchf & 7u;
+                                    const bool nonfin = !(__builtin_fabsf(tw.x) < __builtin_inff() && __builtin_fabsf(tw.y) < __builtin_inff() && __builtin_fabsf(tw.z) < __builtin_inff());
+                                    float4* rec = stack_rec(sp, slot);
+                                    rec[0] = make_float4(xin.x, xin.y, xin.z, __uint_as_float((depth + 1u) | ((br | (1u << depth) | ((branchf & 8u) | (nonfin ? 8u : 0u))) << 16)));
+                                    rec[1] = make_float4(tdir.x, tdir.y, tdir.z, __uint_as_float(rbase - ((br << 29) | (depth << 2)) * kGolden));   // k0
+                                    rec[2] = make_float4(tw.x, tw.y, tw.z, __uint_as_float(k1));
+                                    rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);              // completes the line: no partial-line write
+                                    ++sp;
+                                }
+                                nf = f * Re;
+                            } else {
+                                const float Pr = 0.25f + 0.5f * Re;                         // :256
+                                const bool pick_refl = rng_draw(rbase + kGolden, k1) < Pr;  // :257
+                                const float inv = rcp_exact(pick_refl ? Pr : 1.f - Pr);     // :259 / :263
+                                nf = f * (pick_refl ? Re : Tr) * inv;
+                                if (!pick_refl) { no = xin; nd = tdir; }
+                            }
+                        }
+                    }
+                    // extend() smallpt.cpp:120-123 + D18 + D19
+                    w = w * nf;
+                    o = no; d = nd;
+                    ++depth;
+                    rbase += 4u * kGolden;
+                    if (depth >= SPT_K_MAX_DEPTH) ++nkill;
+                    else if (!(w.x == 0.f && w.y == 0.f && w.z == 0.f)) { has_ray = true; to_gen = false; }
+                    if (!(__builtin_fabsf(w.x) < __builtin_inff() && __builtin_fabsf(w.y) < __builtin_inff() && __builtin_fabsf(w.z) < __builtin_inff())) branchf |= 8u;
+                }
+            }
+            if (has_ray) {
+                sq[2] = make_float4(w.x, w.y, w.z, __uint_as_float(k1));
+                sq[3].x = __uint_as_float(rbase);
+            } else if (to_gen) {
+                sq[1].w = __uint_as_float(pack_q(depth, branchf, sp));   // the count of the sample's pending transmitted children for the GEN visit
+            }
+            QSTAMP(3)
+        }
+
+        // ================= BEGIN: ray test, always-tested spheres, start of the walk (spt_grid.h (1), (4)) =================
+        nbounce += (unsigned long long)__popcll(__ballot(has_ray));
+        {
+            typedef const __attribute__((address_space(4))) GridParams* GArgs;
+            GArgs gp = (GArgs)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KParams));
+            asm volatile("" : "+s"(gp));
+            const GridParams& GB = *(const GridParams*)gp;
+            bool ok = false;
+            float t_ok = __builtin_inff();
+            uint32_t bkey = kQInfKey, bi = 0u;                   // index 0 with the inf key: never replaced by another inf key, never taken for a hit
+            if (has_ray) {
+                ok = grid_ray_ok(GB, o.x, o.y, o.z, d.x, d.y, d.z, t_ok);
+                if (!ok) t_ok = __builtin_inff();                // the exhaustive loop's answer needs no range
+                sq[0] = make_float4(o.x, o.y, o.z, t_ok);
+                sq[1] = make_float4(d.x, d.y, d.z, __uint_as_float(pack_q(depth, branchf, sp)));
+            }
+            for (uint32_t k = 0; k < G.nalways; ++k) {           // ascending indices, strict '<' (smallpt.cpp:61)
+                const uint32_t i = s_refs[G.nrefs + k];
+                const float4 g = s_geom[i];
+                if (has_ray && ok) {
+                    const uint32_t key = sphere_key_q(g, o, d);
+                    if (key < bkey) { bkey = key; bi = i; }
+                }
+            }
+            const unsigned long long bad = __ballot(has_ray && !ok);
+            if (bad != 0ull) {                                   // spt_grid.h (4): the exhaustive loop of smallpt.cpp:54-70, in place
+                if (STATS) st_redo += (unsigned long long)__popcll(bad);
+                for (uint32_t i = 0; i < G.n; ++i) {
+                    const float4 g = s_geom[i];
+                    if (has_ray && !ok) {
+                        const uint32_t key = sphere_key_q(g, o, d);
+                        if (key < bkey) { bkey = key; bi = i; }
+                    }
+                }
+                if (has_ray && !ok) {
+                    reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(bkey, bi);
+                    requeue = (bkey != kQInfKey && (__float_as_uint(s_mat[bi].w) & 3u) == 2u) ? 2u : 1u;
+                }
+            }
+            const bool begun = has_ray && ok;
+            const unsigned long long mb = __ballot(begun);
+            if (begun) {
+                GridWalk gw;
+                grid_walk_begin(GB, o.x, o.y, o.z, d.x, d.y, d.z, gw);
+                const uint32_t pos = nR + rank_q(mb);
+                RD0[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(bkey));
+                RD1[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(bi | (slot << 16)));
+                RD2[pos] = make_float4(gw.tx, gw.ty, gw.tz, __uint_as_float(gw.ci));
+                RD3[pos] = make_uint2(s_cellh[gw.ci], s_cellr[gw.ci]);
+            }
+            nR += (uint32_t)__popcll(mb);
+        }
+        // ================= push the slots that did not begin a walk =================
+        {
+            const unsigned long long mg = __ballot(to_gen), mh = __ballot(requeue == 1u), mr = __ballot(requeue == 2u);
+            if (to_gen) LGN[nG + rank_q(mg)] = (uint8_t)slot;
+            if (requeue == 1u) LH[nH + rank_q(mh)] = (uint8_t)slot;
+            if (requeue == 2u) LH[S - 1u - nHR - rank_q(mr)] = (uint8_t)slot;
+            nG += (uint32_t)__popcll(mg); nH += (uint32_t)__popcll(mh); nHR += (uint32_t)__popcll(mr);
+        }
+        QSTAMP(cls == QC_GEN ? 2 : 3)
+        }
+
+        if (idle) break;
+    }
+#undef QSTAMP
+
+    // stats: wave reduction then one atomic per wave
+    unsigned long long nk = nkill, ns = st_step, nt = st_test;
+    for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off); if (STATS) { ns += __shfl_down(ns, off); nt += __shfl_down(nt, off); } }
+    if (lane == 0) {
+        atomicAdd(&K.counters[0], nbounce);
+        if (nk) atomicAdd(&K.counters[1], nk);
+        if (timed_out) atomicAdd(&K.counters[8], 1ull);
+        if (STATS) {
+            atomicAdd(&K.counters[2], ns); atomicAdd(&K.counters[3], nt);
+            atomicAdd(&K.counters[4], st_iter); atomicAdd(&K.counters[5], st_act);
+            atomicAdd(&K.counters[6], st_redo); atomicAdd(&K.counters[7], st_exch);
+            atomicAdd(&K.counters[9], st_fin);
+            for (int i = 0; i < 3; ++i) { atomicAdd(&K.counters[10 + i], st_bat[i]); atomicAdd(&K.counters[13 + i], st_lan[i]); }
+            for (int i = 0; i < 4; ++i) atomicAdd(&K.counters[16 + i], ph[i]);
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            atomicAdd(&K.counters[20], t_end - t_start);
+            atomicMax(&K.counters[21], t_end - t_start);             // longest wave
+            if (t_dry) { atomicMax(&K.counters[22], t_end - t_dry); atomicAdd(&K.counters[23], t_end - t_dry); }   // longest / summed drain after the queue ran dry
+        }
+    }
+}
+
+}  // namespace spt
+
+// LDS of one workgroup: the grid tables + 16 bytes of material per sphere, then per wave R begun walks of 56 bytes and two byte lists of S entries
+extern "C" size_t spt_gpool_lds_bytes(const spt::GridParams* G, uint32_t waves, uint32_t S, uint32_t R)
+{
+    const size_t ngeom = G->n ? G->n : 1u;
+    const size_t tables = ((ngeom * 16u + (size_t)G->ncells * 8u + (((size_t)G->nrefs + G->nalways + 2u) / 2u) * 4u + 15u) & ~(size_t)15u) + ngeom * 16u;
+    return tables + (size_t)waves * ((size_t)R * 56u + 2u * (size_t)S);
+}
+extern "C" size_t spt_gpool_slot_floats(uint32_t blocks, uint32_t waves, uint32_t S) { return (size_t)blocks * waves * S * (spt::kQSlotF4 * 4u); }
+extern "C" size_t spt_gpool_stack_floats(uint32_t blocks, uint32_t waves, uint32_t S) { return (size_t)blocks * waves * S * (3u * spt::kQStackF4 * 4u); }
+
+extern "C" hipError_t spt_gpool_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
+                                       const uint32_t* d_always, const spt::QParams* Q, uint32_t blocks, uint32_t threads, int stats, hipStream_t stream)
+{
+    if (threads == 0 || threads > (uint32_t)spt::kQBlock || (threads & 63u)) return hipErrorInvalidValue;
+    if (Q->S == 0 || Q->S > 256u || (Q->S & 15u) || (Q->R & 3u) || Q->R == 0 || Q->R > 0xFFFFu || Q->drain == 0 || Q->drain > 64u || G->n > 0xFFFFu) return hipErrorInvalidValue;
+    const size_t lds = spt_gpool_lds_bytes(G, threads / 64u, Q->S, Q->R);
+    if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+    const void* fn = stats ? reinterpret_cast<const void*>(&spt::gpoolkernel<true>) : reinterpret_cast<const void*>(&spt::gpoolkernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (stats) hipLaunchKernelGGL(spt::gpoolkernel<true>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, *Q);
+    else hipLaunchKernelGGL(spt::gpoolkernel<false>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, *Q);
+    return hipGetLastError();
+}

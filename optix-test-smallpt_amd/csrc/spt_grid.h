@@ -95,19 +95,28 @@ SPT_HD bool grid_ray_ok(const GridParams& G, float ox, float oy, float oz, float
     return (far2 <= G.dfar2_max) & (eta < 0.25f);               // (eta < 1/4: a direction that is no direction at all; also refuses NaN)
 }
 
+// One axis of a walk's constants: 1 / d, whether the ray moves along the axis at all, parameter per cell, direction of the index step.
+// (Also what a walker lane of spt_gpool.hip rebuilds from the direction when it takes a begun walk over: a walk's state in LDS is
+// {exit parameters, cell index} only.)
+SPT_HD void grid_axis_rate(float d, float cell, float& iv, bool& moving, float& dt, bool& neg)
+{
+    iv = grid_rcp(d);
+    moving = __builtin_fabsf(d) >= 0x1p-60f;                      // else the ray never crosses a face of this axis (and iv may be inf)
+    dt = moving ? cell * __builtin_fabsf(iv) : 0.0f;
+    neg = !(d > 0.0f);
+}
+
 // One axis of the start of a walk: cell index (clamped into the table), exit parameter, parameter per cell, index step.
 SPT_HD void grid_axis_begin(float o, float d, float gmin, float cell, float inv_cell, int32_t dim,
                             int32_t& idx, float& t, float& dt, bool& neg)
 {
     const float f = (o - gmin) * inv_cell;
     const int32_t i = (int32_t)__builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)(dim - 1));   // clamped into the table (NaN -> 0)
-    const bool pos = d > 0.0f;
-    const float b = gmin + (float)(i + (pos ? 1 : 0)) * cell;     // the face the ray leaves the cell through
-    const float iv = grid_rcp(d);
-    const bool moving = __builtin_fabsf(d) >= 0x1p-60f;           // else the ray never crosses a face of this axis (and iv may be inf)
+    float iv;
+    bool moving;
+    grid_axis_rate(d, cell, iv, moving, dt, neg);
+    const float b = gmin + (float)(i + (neg ? 0 : 1)) * cell;     // the face the ray leaves the cell through
     t = moving ? (b - o) * iv : __builtin_inff();
-    dt = moving ? cell * __builtin_fabsf(iv) : 0.0f;
-    neg = !pos;
     idx = i;
 }
 

@@ -69,9 +69,24 @@ struct MParams {
     uint32_t nalways, sphere_mode;
 };
 
+// Grid-pool kernel (spt_gpool.hip): the launch parameters besides KParams / GridParams
+struct QParams {
+    float4* slots;                 // waves x S x 6 float4: the path state of every slot (global memory, cache resident)
+    uint32_t S;                    // path slots per wave (multiple of 16, <= 256)
+    uint32_t R;                    // begun walks a wave can hold in LDS (56 bytes each; multiple of 4)
+    uint32_t drain;                // walker lanes that must be finished / empty before the wave stops walking to exchange them
+    uint32_t min_batch;            // smallest shading / generation batch worth running while the walkers starve
+    uint32_t walk_iters;           // walk iterations between the issue of a batch's loads and the batch's code
+};
+
 }  // namespace spt
 
 namespace spt { struct GridParams; }
+extern "C" size_t spt_gpool_lds_bytes(const spt::GridParams* G, uint32_t waves, uint32_t S, uint32_t R);
+extern "C" size_t spt_gpool_slot_floats(uint32_t blocks, uint32_t waves, uint32_t S);
+extern "C" size_t spt_gpool_stack_floats(uint32_t blocks, uint32_t waves, uint32_t S);
+extern "C" hipError_t spt_gpool_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
+                                       const uint32_t* d_always, const spt::QParams* Q, uint32_t blocks, uint32_t threads, int stats, hipStream_t stream);
 extern "C" size_t spt_grid_lds_bytes(const spt::GridParams* G);
 extern "C" int spt_grid_block_threads(void);
 extern "C" size_t spt_grid_stack_floats(uint32_t blocks, uint32_t threads);

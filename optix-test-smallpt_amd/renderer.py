@@ -210,8 +210,9 @@ class Renderer:
 
     def last_kernel(self):
         """'pool' (spt_pool.hip, material-sorted), 'mega' (spt_kernel.hip), 'mesh' (spt_mesh.hip, triangles), 'sbvh' (spt_mesh.hip over a
-        sphere hierarchy) or 'grid' (spt_grid.hip, uniform grid over a large sphere table) for the last launch."""
-        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh", 4: "grid"}[self._lib.spt_last_kernel(self._h)]
+        sphere hierarchy), 'gpool' (spt_gpool.hip, uniform grid over a large sphere table driven by wave-private path pools: the default above 24
+        spheres) or 'grid' (spt_grid.hip, the same grid with lanes that own their path: tables that leave no LDS for the pools) for the last launch."""
+        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh", 4: "grid", 5: "gpool"}[self._lib.spt_last_kernel(self._h)]
 
     def render_interleaved_device(self, out_tensor, w, h, block_rows, world, rank, samps_per_cell, seed=0,
                                   normalise=False, camera=None, stream=None):
