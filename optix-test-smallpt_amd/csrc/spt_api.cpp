@@ -852,7 +852,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         P.watchdog_ticks = c->watchdog_ticks;
         const uint32_t lsel = (c->variant >> 16) & 0xFFu;
         // ---- round 4: wave-private path pools with register-resident walkers (spt_gpool.hip) whenever the tables leave the LDS for
-        // them: R begun walks of 48 bytes + two byte lists per wave beside the grid tables.  Tuning bit 24 keeps the lane-owned kernel
+        // them: R begun walks of 64 bytes + two byte lists per wave beside the grid tables.  Tuning bit 24 keeps the lane-owned kernel
         // (A/B); SPT_GPOOL="S,R,drain,min_batch[,walk_iters]" overrides the pool geometry (experiments). ----
         if (!(c->variant & 0x1000000u)) {
             static const char* env = std::getenv("SPT_GPOOL");
@@ -861,7 +861,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
             const uint32_t waves = threads / 64u;
             const size_t fixed = spt_gpool_lds_bytes(&c->grid, waves, S, 0);
             const size_t room = fixed < (size_t)160 * 1024 ? (size_t)160 * 1024 - fixed : 0;
-            uint32_t R = (uint32_t)(room / ((size_t)waves * 56u)) & ~3u;
+            uint32_t R = (uint32_t)(room / ((size_t)waves * 64u)) & ~3u;
             if (R > Rwant) R = Rwant & ~3u;
             if (R >= 48u && c->n <= 0xFFFFu) {
                 const size_t stack_floats = spt_gpool_stack_floats(blocks, waves, S);

@@ -67,42 +67,30 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 {
     extern __shared__ float4 s_geom[];                           // n sphere records, then the grid tables, then the wave regions
     const uint32_t ngeom = G.n ? G.n : 1u;
-    // cell headers of 8 bytes: {first reference << 13 | count (kGridBorder on the border), reference 0 | reference 1 << 16} -- the
-    // first two spheres of a cell are known as soon as its header is, without the round trip through the reference list
-    uint32_t* const s_cellh = reinterpret_cast<uint32_t*>(s_geom + ngeom);      // (two arrays: two independent 4-byte reads, no register pair)
-    uint32_t* const s_cellr = s_cellh + G.ncells;
-    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_cellr + G.ncells);   // nrefs cell references, then the always-tested list, one spare
+    uint32_t* const s_cells = reinterpret_cast<uint32_t*>(s_geom + ngeom);      // cell headers: first reference << 13 | count, kGridBorder on the border
+    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_cells + G.ncells);   // nrefs cell references, then the always-tested list, one spare
     // materials: {color.xyz, Refl_t | emissive << 2} per sphere (16 of the host table's 48 bytes: pmax = fmaxf(color) and color * (1 / pmax)
     // are single IEEE operations that the shading batch repeats bit for bit; emission is read from global memory for emissive spheres only)
-    const uint32_t tables_bytes = (ngeom * 16u + G.ncells * 8u + ((G.nrefs + G.nalways + 2u) >> 1) * 4u + 15u) & ~15u;
+    const uint32_t tables_bytes = (ngeom * 16u + G.ncells * 4u + ((G.nrefs + G.nalways + 2u) >> 1) * 4u + 15u) & ~15u;
     float4* const s_mat = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_geom) + tables_bytes);
     for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) {
         s_geom[i] = K.geom[i];
         const float4 mc = K.mat[3 * i + 1];
         s_mat[i] = make_float4(mc.x, mc.y, mc.z, K.mat[3 * i].w);
     }
-    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) {
-        const uint32_t h = g_cells[i];
-        uint32_t r01 = 0u;
-        if (h != kGridBorder) {
-            const uint32_t first = h >> kGridCountBits, cnt = h & ((1u << kGridCountBits) - 1u);
-            if (cnt > 0u) r01 = g_refs[first];
-            if (cnt > 1u) r01 |= (uint32_t)g_refs[first + 1u] << 16;
-        }
-        s_cellh[i] = h; s_cellr[i] = r01;
-    }
+    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) s_cells[i] = g_cells[i];
     for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_refs[i] = g_refs[i];
     for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
 
     const uint32_t lane = lane_id_q();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t S = Q.S, R = Q.R;
-    const uint32_t wave_bytes = R * 56u + 2u * S;
+    const uint32_t wave_bytes = R * 64u + 2u * S;
     float4* const RD0 = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_geom) + tables_bytes + ngeom * 16u + wave * wave_bytes);   // {o.xyz, near key}
     float4* const RD1 = RD0 + R;                                 // {d.xyz, near index | slot << 16}
     float4* const RD2 = RD1 + R;                                 // {tx, ty, tz, cell index}
-    uint2* const RD3 = reinterpret_cast<uint2*>(RD2 + R);        // header of the walk's start cell
-    uint8_t* const LH = reinterpret_cast<uint8_t*>(RD3 + R);     // S bytes: HIT list from index 0 up, HITR list from S - 1 down
+    float4* const RD3 = RD2 + R;                                 // {dtx, dty, dtz, header of the walk's start cell}
+    uint8_t* const LH = reinterpret_cast<uint8_t*>(RD3 + R);    // S bytes: HIT list from index 0 up, HITR list from S - 1 down
     uint8_t* const LGN = LH + S;                                 // S bytes: GEN list
     const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave;
     float4* const slots = Q.slots + (size_t)wave_gid * S * kQSlotF4;
@@ -133,29 +121,24 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
     unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = 0;           // wave time: walk, exchange, generation batches, shading batches
 #define QSTAMP(i) if (STATS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
 
-    // ---- the lane's walk (registers).  wj <= wcnt: walking in a cell of wcnt references of which wj are tested (wj == wcnt: the cell is
-    // exhausted, the lane steps); wj > wcnt (1, 0): the lane holds no walk.  wfin != 0: the lane's walk has ended and waits for the
-    // exchange.  The walk runs one cell AHEAD of the tests: (wtx, wty, wtz, wci) belong to the cell after the current one, nh is that
-    // cell's header -- in flight while the current cell's spheres are tested -- and mex the parameter at which the ray leaves the
-    // current cell (what the stop rule of spt_grid.h (3) compares with the nearest hit).  The arithmetic and its order are those of
-    // grid_walk_exit / grid_walk_step, evaluated one cell early. ----
+    // ---- the lane's walk (registers): the fields of a GridWalk (spt_grid.h), the ray, the nearest (key, index) so far and the references
+    // [cur, end) of the current cell that are still to test.  cur == end: the cell is exhausted, the lane steps; cur > end (1, 0): the
+    // lane holds no walk.  wfin != 0: the lane's walk has ended and waits for the exchange. ----
     uint32_t wfin = 0;
     f3 wo = mk(0, 0, 0), wd = mk(0, 0, 1);
-    float wtx = 0.f, wty = 0.f, wtz = 0.f, wdx = 0.f, wdy = 0.f, wdz = 0.f, mex = 0.f;
+    float wtx = 0.f, wty = 0.f, wtz = 0.f, wdx = 0.f, wdy = 0.f, wdz = 0.f;
     int32_t wsx = 0, wsy = 0, wsz = 0;
-    uint32_t wci = 0, wj = 1, wcnt = 0, wfirst = 0, wr01 = 0, nref = 0, near_key = kQInfKey, near_i = 0, wslot = 0;
-    uint32_t nhx = kGridBorder, nhy = 0u;
+    uint32_t wci = 0, cur = 1, end = 0, near_key = kQInfKey, near_i = 0, wslot = 0;
 
-    // the grid constants a walker lane needs when it takes a begun walk over: in VECTOR registers (in scalar ones they push the
-    // loop's masks into spill lanes; re-read from the kernel-argument segment they put a scalar-memory wait into every exchange)
-    float cellx = G.cell[0], celly = G.cell[1], cellz = G.cell[2];
+    // the index steps a walker lane needs when it takes a begun walk over: in VECTOR registers (in scalar ones they push the loop's
+    // masks into spill lanes; re-read from the kernel-argument segment they put a scalar-memory wait into every exchange)
     int32_t stride_y = G.stride_y, stride_z = G.stride_z;
-    asm volatile("" : "+v"(cellx), "+v"(celly), "+v"(cellz), "+v"(stride_y), "+v"(stride_z));
+    asm volatile("" : "+v"(stride_y), "+v"(stride_z));
 
     if (STATS) ph_t = __builtin_amdgcn_s_memtime();
     for (;;) {
         if ((++n_loop & 63u) == 0u && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
-        uint32_t nAct = (uint32_t)__popcll(__ballot(wj <= wcnt));
+        uint32_t nAct = (uint32_t)__popcll(__ballot(cur <= end));
         uint32_t nFin = (uint32_t)__popcll(__ballot(wfin != 0u));
         const uint32_t nEmp = 64u - nAct - nFin;
         bool idle = true;                                        // nothing was done in this round: the wave's tasks are finished
@@ -166,15 +149,14 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             idle = false;
             // (finished lanes are empty lanes already -- cur > end --, so the begun walks can be fetched before the hits are handed over:
             // the LDS reads of both halves are in flight together)
-            const unsigned long long me = __ballot(wj > wcnt);
+            const unsigned long long me = __ballot(cur > end);
             const uint32_t ne = (uint32_t)__popcll(me);
             const uint32_t k = ne < nR ? ne : nR;
             const uint32_t rk = rank_q(me);
-            const bool take = wj > wcnt && rk < k;
+            const bool take = cur > end && rk < k;
             const uint32_t pos = take ? nR - 1u - rk : 0u;
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            uint2 h0 = make_uint2(0u, 0u);
-            if (take) { r0 = RD0[pos]; r1 = RD1[pos]; r2 = RD2[pos]; h0 = RD3[pos]; }
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+            if (take) { r0 = RD0[pos]; r1 = RD1[pos]; r2 = RD2[pos]; r3 = RD3[pos]; }
             uint32_t hcls = 0u;                                  // 1: onto HIT, 2: onto HITR
             if (wfin != 0u) {
                 reinterpret_cast<uint2*>(slots + wslot * kQSlotF4 + 4)[0] = make_uint2(near_key, near_i);
@@ -185,21 +167,16 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             nH += (uint32_t)__popcll(mh); nHR += (uint32_t)__popcll(mr);
             wfin = 0u;
             if (take) {
+                // a begun walk as grid_walk_begin left it (spt_grid.h); the index steps follow from the direction's signs as there
                 wo = mk(r0.x, r0.y, r0.z); near_key = __float_as_uint(r0.w);
                 wd = mk(r1.x, r1.y, r1.z);
                 const uint32_t pk = __float_as_uint(r1.w);
                 near_i = pk & 0xFFFFu; wslot = pk >> 16;
                 wtx = r2.x; wty = r2.y; wtz = r2.z; wci = __float_as_uint(r2.w);
-                // the walk's constants from the direction (spt_grid.h grid_axis_rate: what grid_walk_begin computed)
-                float iv; bool mv, ngx, ngy, ngz;
-                grid_axis_rate(wd.x, cellx, iv, mv, wdx, ngx);
-                grid_axis_rate(wd.y, celly, iv, mv, wdy, ngy);
-                grid_axis_rate(wd.z, cellz, iv, mv, wdz, ngz);
-                wsx = ngx ? -1 : 1; wsy = ngy ? -stride_y : stride_y; wsz = ngz ? -stride_z : stride_z;
-                wfirst = h0.x >> kGridCountBits; wcnt = h0.x & ((1u << kGridCountBits) - 1u); wj = 0u; wr01 = h0.y;   // the start cell (never a border cell)
-                mex = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));                   // grid_walk_exit of the start cell
-                grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, mex);  // one cell ahead
-                nhx = s_cellh[wci]; nhy = s_cellr[wci];
+                wdx = r3.x; wdy = r3.y; wdz = r3.z;
+                wsx = !(wd.x > 0.0f) ? -1 : 1; wsy = !(wd.y > 0.0f) ? -stride_y : stride_y; wsz = !(wd.z > 0.0f) ? -stride_z : stride_z;
+                const uint32_t h0 = __float_as_uint(r3.w);       // the start cell (never a border cell)
+                cur = h0 >> kGridCountBits; end = cur + (h0 & ((1u << kGridCountBits) - 1u));
             }
             nR -= k;
             nAct += k; nFin = 0u;
@@ -248,40 +225,32 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             if ((nR != 0u || (cap >= minb && nR < Q.drain)) && 64u - Q.drain > thr) thr = 64u - Q.drain;
             uint32_t iters = run_batch ? Q.walk_iters : 0xFFFFFFFFu;
             for (;;) {
-                if (STATS) { ++st_iter; st_act += (uint32_t)__popcll(__ballot(wj <= wcnt)); }
-                // The LDS reads of an iteration are issued by EVERY lane, outside the exec-masked blocks (lanes that do not need them
-                // re-read what they hold, idle lanes read valid stale addresses): their number per iteration is then fixed, the
-                // compiler waits with counted lgkmcnt(N), and only the sphere record's round trip is exposed -- the header of the next
-                // cell and the reference after next arrive while the test's arithmetic runs.
-                if (wj == wcnt) {
+                if (STATS) { ++st_iter; st_act += (uint32_t)__popcll(__ballot(cur <= end)); }
+                if (cur == end) {
                     // ---- STEP: all spheres of the cell are tested; leave it (spt_grid.h (3)) ----
+                    const float m = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));   // grid_walk_exit
                     const float near_t = __uint_as_float(near_key + kQEpsBias);    // 1e20 while nothing is hit
-                    if (mex < near_t && nhx != kGridBorder) {    // else: every cell up to the hit has been visited, or the ray has left the table
-                        wfirst = nhx >> kGridCountBits; wcnt = nhx & ((1u << kGridCountBits) - 1u); wj = 0u; wr01 = nhy;
-                        mex = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));           // grid_walk_exit of the cell just entered
-                        grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, mex);
-                    } else {
-                        wj = 1u; wcnt = 0u; wfin = 1u;
+                    uint32_t h = kGridBorder;
+                    if (m < near_t) {                            // else: every cell up to the hit has been visited
+                        grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, m);
+                        h = s_cells[wci];
                     }
+                    if (h != kGridBorder) { cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u)); }
+                    else { cur = 1u; end = 0u; wfin = 1u; }      // ... or the ray has left the table
                     if (STATS) st_step += 1;                     // (per lane; reduced at the end)
                 }
-                nhx = s_cellh[wci]; nhy = s_cellr[wci];          // header of the cell after the current one (consumed by the lane's next STEP)
-                // the next sphere of the lane's cell: the first two come with the header, the others from the list one iteration ahead
-                const uint32_t ti = wj == 0u ? (wr01 & 0xFFFFu) : (wj == 1u ? wr01 >> 16 : nref);
-                const float4 tg = s_geom[ti];
-                const bool testing = wj < wcnt;
-                wj += testing ? 1u : 0u;
-                nref = s_refs[wfirst + wj];                      // (wj <= wcnt: inside the list or its spare entry)
-                if (testing) {
-                    // ---- TEST ----
-                    const uint32_t key = sphere_key_q(tg, wo, wd);
+                if (cur < end) {
+                    // ---- TEST: the next sphere of the lane's cell ----
+                    const uint32_t ti = s_refs[cur];
+                    ++cur;
+                    const uint32_t key = sphere_key_q(s_geom[ti], wo, wd);
                     // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
                     const bool better = (key < near_key) | ((key == near_key) & (ti < near_i));
                     near_key = better ? key : near_key;
                     near_i = better ? ti : near_i;
                     if (STATS) st_test += 1;
                 }
-                if ((uint32_t)__popcll(__ballot(wj <= wcnt)) <= thr || --iters == 0u) break;
+                if ((uint32_t)__popcll(__ballot(cur <= end)) <= thr || --iters == 0u) break;
             }
             QSTAMP(0)
         }
@@ -592,7 +561,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                 RD0[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(bkey));
                 RD1[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(bi | (slot << 16)));
                 RD2[pos] = make_float4(gw.tx, gw.ty, gw.tz, __uint_as_float(gw.ci));
-                RD3[pos] = make_uint2(s_cellh[gw.ci], s_cellr[gw.ci]);
+                RD3[pos] = make_float4(gw.dtx, gw.dty, gw.dtz, __uint_as_float(s_cells[gw.ci]));
             }
             nR += (uint32_t)__popcll(mb);
         }
@@ -639,8 +608,8 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 extern "C" size_t spt_gpool_lds_bytes(const spt::GridParams* G, uint32_t waves, uint32_t S, uint32_t R)
 {
     const size_t ngeom = G->n ? G->n : 1u;
-    const size_t tables = ((ngeom * 16u + (size_t)G->ncells * 8u + (((size_t)G->nrefs + G->nalways + 2u) / 2u) * 4u + 15u) & ~(size_t)15u) + ngeom * 16u;
-    return tables + (size_t)waves * ((size_t)R * 56u + 2u * (size_t)S);
+    const size_t tables = ((ngeom * 16u + (size_t)G->ncells * 4u + (((size_t)G->nrefs + G->nalways + 2u) / 2u) * 4u + 15u) & ~(size_t)15u) + ngeom * 16u;
+    return tables + (size_t)waves * ((size_t)R * 64u + 2u * (size_t)S);
 }
 extern "C" size_t spt_gpool_slot_floats(uint32_t blocks, uint32_t waves, uint32_t S) { return (size_t)blocks * waves * S * (spt::kQSlotF4 * 4u); }
 extern "C" size_t spt_gpool_stack_floats(uint32_t blocks, uint32_t waves, uint32_t S) { return (size_t)blocks * waves * S * (3u * spt::kQStackF4 * 4u); }
