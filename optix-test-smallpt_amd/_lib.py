@@ -79,6 +79,7 @@ INTERNAL_SYMBOLS = {
     "spt_selftest_sphere_grid": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_char_p, C.c_uint32]),
     "spt_selftest_bvh": (C.c_int, [C.POINTER(SptMesh), C.c_uint32, C.POINTER(C.c_uint32 * 4), C.c_char_p, C.c_uint32]),
     "spt_set_tuning": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "spt_set_grid_pools": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "spt_diag": (C.c_int, [_P, C.POINTER(C.c_uint64 * 24)]),
     "spt_selftest_math": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint32, C.c_uint32]),
     "spt_selftest_range": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),

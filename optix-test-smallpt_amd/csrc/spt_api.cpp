@@ -95,6 +95,10 @@ struct spt_ctx {
     // tuning
     uint32_t blocks_per_cu = 0;
     uint32_t variant = 0;
+    // grid kernels: 0 = wave-private path pools (spt_gpool.hip) whenever the LDS has room for them, 1 = lanes own their path (spt_grid.hip);
+    // pool geometry {slots per wave, begun walks per wave, drain, smallest batch, walk iterations behind a batch's loads} (spt_set_grid_pools)
+    int grid_lane_owned = 0;
+    uint32_t gq[5] = {192u, 96u, 24u, 32u, 4u};
     // pool kernel, cost-ordered dispatch (spt_kernel.h KParams::chunk_order): tables of the last pool launch and the view they belong to
     uint32_t* d_chunk_tables = nullptr;   // order[cap] | clock[2 * cap] | 512 words of the sorting kernels
     size_t chunk_cap = 0;
@@ -224,6 +228,17 @@ void spt_destroy(spt_ctx* c)
     if (c->ev_acc) (void)hipEventDestroy(c->ev_acc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int spt_set_grid_pools(spt_ctx* c, int lane_owned, uint32_t slots, uint32_t ready, uint32_t drain, uint32_t min_batch, uint32_t walk_iters)
+{
+    if (!c) return 1;
+    if (slots > 256u || (slots & 15u) || ready > 0xFFFFu || drain > 64u)
+        return c->fail("spt_set_grid_pools: slots must be a multiple of 16 up to 256, ready <= 65535, drain <= 64");
+    c->grid_lane_owned = lane_owned ? 1 : 0;
+    const uint32_t def[5] = {192u, 96u, 24u, 32u, 4u}, in[5] = {slots, ready & ~3u, drain, min_batch, walk_iters};
+    for (int i = 0; i < 5; ++i) c->gq[i] = in[i] ? in[i] : def[i];
+    return 0;
 }
 
 int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
@@ -852,18 +867,18 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         P.watchdog_ticks = c->watchdog_ticks;
         const uint32_t lsel = (c->variant >> 16) & 0xFFu;
         // ---- round 4: wave-private path pools with register-resident walkers (spt_gpool.hip) whenever the tables leave the LDS for
-        // them: R begun walks of 64 bytes + two byte lists per wave beside the grid tables.  Tuning bit 24 keeps the lane-owned kernel
-        // (A/B); SPT_GPOOL="S,R,drain,min_batch[,walk_iters]" overrides the pool geometry (experiments). ----
-        if (!(c->variant & 0x1000000u)) {
+        // them: R begun walks of 64 bytes + two byte lists per wave beside the grid tables.  spt_set_grid_pools (internal) keeps the
+        // lane-owned kernel or changes the pool geometry; SPT_GPOOL="S,R,drain,min_batch[,walk_iters]" overrides it per process (tools). ----
+        if (!c->grid_lane_owned) {
             static const char* env = std::getenv("SPT_GPOOL");
-            uint32_t S = 192, Rwant = 96, drain = 24, minb = 32, witers = 4;
+            uint32_t S = c->gq[0], Rwant = c->gq[1], drain = c->gq[2], minb = c->gq[3], witers = c->gq[4];
             if (env) { unsigned a = 0, b2 = 0, d2 = 0, m2 = 0, w2 = 0; const int got = std::sscanf(env, "%u,%u,%u,%u,%u", &a, &b2, &d2, &m2, &w2); if (got >= 4) { S = a; Rwant = b2; drain = d2; minb = m2; } if (got == 5) witers = w2; }
             const uint32_t waves = threads / 64u;
             const size_t fixed = spt_gpool_lds_bytes(&c->grid, waves, S, 0);
             const size_t room = fixed < (size_t)160 * 1024 ? (size_t)160 * 1024 - fixed : 0;
             uint32_t R = (uint32_t)(room / ((size_t)waves * 64u)) & ~3u;
             if (R > Rwant) R = Rwant & ~3u;
-            if (R >= 48u && c->n <= 0xFFFFu) {
+            if (R >= 48u && c->n <= 0xC000u && c->grid.nrefs < 0x7FFEu) {
                 const size_t stack_floats = spt_gpool_stack_floats(blocks, waves, S);
                 const size_t need = stack_floats + spt_gpool_slot_floats(blocks, waves, S);
                 if (need > c->stack_cap) {

@@ -31,7 +31,9 @@ namespace spt {
 constexpr int kQBlock = 1024;                                    // threads per workgroup (one workgroup per CU shares the LDS tables)
 constexpr uint32_t kQEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) + 1
 constexpr uint32_t kQInfKey = 0x60AD78ECu - kQEpsBias;           // key of 1e20f (maths.h:16)
+constexpr uint32_t kQSlotBytes = 96;                             // = 16 kQSlotF4
 constexpr int kQSlotF4 = 6;                                      // float4 per slot in global memory
+constexpr uint32_t kQFin = 0xFFFFu;                              // staged header of a border cell / the walker's cur when its walk has ended
 constexpr int kQStackF4 = 4;                                     // one pending child = one 64-byte line
 
 __device__ __forceinline__ uint32_t lane_id_q() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -53,6 +55,25 @@ __device__ __forceinline__ uint32_t sphere_key_q(const float4 g, f3 o, f3 d)
     return key1 < key2 ? key1 : key2;
 }
 
+// LDS reads at a byte address the lane holds in a register (the kernel's dynamic LDS starts at address 0 -- this translation unit has no
+// static __shared__ --, so offsets into s_lds ARE addresses; spt_gpool_launch checks it): no base is added, ds_read_u16 zero-extends.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float __attribute__((ext_vector_type(4))) lds_v4f;
+// (ds_read_u16 written out: the compiler's own selection masks the zero-extended result once more; the wait inside the statement keeps
+// the compiler's counted waits conservative)
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { uint32_t v; asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)a; }
+__device__ __forceinline__ float4 lds_f4(uint32_t a)
+{
+    const lds_v4f v = *(const __attribute__((address_space(3))) lds_v4f*)(uintptr_t)a;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#else
+__device__ __forceinline__ uint32_t lds_u16(uint32_t) { return 0u; }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t) { return 0u; }
+__device__ __forceinline__ float4 lds_f4(uint32_t) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+#endif
+
 // packed word of a slot (Q1.w): [11:0] depth, [14:12] branch bits (D7), [15] weight-may-be-non-finite flag, [31:30] pending
 // transmitted children of the slot's current sample
 __device__ __forceinline__ uint32_t pack_q(uint32_t depth, uint32_t branchf, uint32_t sp) { return depth | (branchf << 12) | (sp << 30); }
@@ -65,35 +86,52 @@ template <bool STATS>
 __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
                                                        const uint16_t* __restrict__ g_refs, const uint32_t* __restrict__ g_always, const QParams Q)
 {
-    extern __shared__ float4 s_geom[];                           // n sphere records, then the grid tables, then the wave regions
+    // LDS of the workgroup: [cell references, always-tested list][sphere records][cell headers][materials][wave regions].
+    // The references come first so that a walker's cur / end are BYTE addresses that fit the 16-bit halves of a staged cell header, and
+    // a reference holds sphere index + gb16 (gb16 = offset of the sphere records / 16): the record's address is reference << 4, one
+    // full-rate instruction, and references order like sphere indices (the lowest-index rule compares them as they are).
+    extern __shared__ char s_lds[];
     const uint32_t ngeom = G.n ? G.n : 1u;
-    uint32_t* const s_cells = reinterpret_cast<uint32_t*>(s_geom + ngeom);      // cell headers: first reference << 13 | count, kGridBorder on the border
-    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_cells + G.ncells);   // nrefs cell references, then the always-tested list, one spare
+    const uint32_t geom_off = ((G.nrefs + G.nalways + 1u) * 2u + 15u) & ~15u;
+    const uint32_t gb16 = geom_off >> 4;
+    const uint32_t cells_off = geom_off + ngeom * 16u;
+    const uint32_t mat_off = (cells_off + G.ncells * 4u + 15u) & ~15u;
+    const uint32_t tables_end = mat_off + ngeom * 16u;
+    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_lds);                  // nrefs cell references, then the always-tested list, one spare
+    float4* const s_geom = reinterpret_cast<float4*>(s_lds + geom_off);          // n x {centre, r * r}
+    uint32_t* const s_cells = reinterpret_cast<uint32_t*>(s_lds + cells_off);    // staged cell headers (below)
     // materials: {color.xyz, Refl_t | emissive << 2} per sphere (16 of the host table's 48 bytes: pmax = fmaxf(color) and color * (1 / pmax)
     // are single IEEE operations that the shading batch repeats bit for bit; emission is read from global memory for emissive spheres only)
-    const uint32_t tables_bytes = (ngeom * 16u + G.ncells * 4u + ((G.nrefs + G.nalways + 2u) >> 1) * 4u + 15u) & ~15u;
-    float4* const s_mat = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_geom) + tables_bytes);
+    float4* const s_mat = reinterpret_cast<float4*>(s_lds + mat_off);
     for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) {
         s_geom[i] = K.geom[i];
         const float4 mc = K.mat[3 * i + 1];
         s_mat[i] = make_float4(mc.x, mc.y, mc.z, K.mat[3 * i].w);
     }
-    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) s_cells[i] = g_cells[i];
-    for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_refs[i] = g_refs[i];
-    for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
+    // cell headers in the walker's form: byte address of the first reference | byte address behind the last << 16 -- the lane's
+    // [cur, end) after two instructions --; a border cell reads kQFin: cur = 0xFFFF > end = 0, "the walk has ended" (the launch
+    // checks 2 (nrefs + 1) < 0xFFFF)
+    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) {
+        const uint32_t h = g_cells[i];
+        const uint32_t first = h >> kGridCountBits, cnt = h & ((1u << kGridCountBits) - 1u);
+        s_cells[i] = h == kGridBorder ? kQFin : ((2u * first) | ((2u * (first + cnt)) << 16));
+    }
+    for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_refs[i] = (uint16_t)(g_refs[i] + gb16);
+    for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_refs[G.nrefs + i] = (uint16_t)((i < G.nalways ? g_always[i] : 0u) + gb16);
 
     const uint32_t lane = lane_id_q();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t S = Q.S, R = Q.R;
     const uint32_t wave_bytes = R * 64u + 2u * S;
-    float4* const RD0 = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_geom) + tables_bytes + ngeom * 16u + wave * wave_bytes);   // {o.xyz, near key}
-    float4* const RD1 = RD0 + R;                                 // {d.xyz, near index | slot << 16}
-    float4* const RD2 = RD1 + R;                                 // {tx, ty, tz, cell index}
+    float4* const RD0 = reinterpret_cast<float4*>(s_lds + tables_end + wave * wave_bytes);             // {o.xyz, near key}
+    float4* const RD1 = RD0 + R;                                 // {d.xyz, near reference (index + gb16) | slot << 16}
+    float4* const RD2 = RD1 + R;                                 // {tx, ty, tz, byte address of the cell header}
     float4* const RD3 = RD2 + R;                                 // {dtx, dty, dtz, header of the walk's start cell}
     uint8_t* const LH = reinterpret_cast<uint8_t*>(RD3 + R);    // S bytes: HIT list from index 0 up, HITR list from S - 1 down
     uint8_t* const LGN = LH + S;                                 // S bytes: GEN list
     const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave;
     float4* const slots = Q.slots + (size_t)wave_gid * S * kQSlotF4;
+    char* const slot_bytes = reinterpret_cast<char*>(slots);     // (32-bit byte offsets from a wave-uniform base: no 64-bit vector arithmetic)
     float4* const gstack = reinterpret_cast<float4*>(K.stack) + (size_t)wave_gid * S * (3 * kQStackF4);
     auto stack_rec = [&](uint32_t e, uint32_t slot) -> float4* { return gstack + (slot * 3u + e) * kQStackF4; };
 
@@ -122,9 +160,9 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 #define QSTAMP(i) if (STATS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
 
     // ---- the lane's walk (registers): the fields of a GridWalk (spt_grid.h), the ray, the nearest (key, index) so far and the references
-    // [cur, end) of the current cell that are still to test.  cur == end: the cell is exhausted, the lane steps; cur > end (1, 0): the
-    // lane holds no walk.  wfin != 0: the lane's walk has ended and waits for the exchange. ----
-    uint32_t wfin = 0;
+    // [cur, end) of the current cell that are still to test (byte addresses in s_refs).  cur == end: the cell is exhausted, the lane
+    // steps; cur > end: the lane is not walking -- (1, 0): it holds no walk, (kQFin, 0): its walk has ended and waits for the exchange.
+    // wci is the byte address of the current cell's header and wsx / wsy / wsz step it; near_i is a reference (sphere index + gb16). ----
     f3 wo = mk(0, 0, 0), wd = mk(0, 0, 1);
     float wtx = 0.f, wty = 0.f, wtz = 0.f, wdx = 0.f, wdy = 0.f, wdz = 0.f;
     int32_t wsx = 0, wsy = 0, wsz = 0;
@@ -132,14 +170,14 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 
     // the index steps a walker lane needs when it takes a begun walk over: in VECTOR registers (in scalar ones they push the loop's
     // masks into spill lanes; re-read from the kernel-argument segment they put a scalar-memory wait into every exchange)
-    int32_t stride_y = G.stride_y, stride_z = G.stride_z;
+    int32_t stride_y = 4 * G.stride_y, stride_z = 4 * G.stride_z;      // (of byte addresses)
     asm volatile("" : "+v"(stride_y), "+v"(stride_z));
 
     if (STATS) ph_t = __builtin_amdgcn_s_memtime();
     for (;;) {
         if ((++n_loop & 63u) == 0u && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
         uint32_t nAct = (uint32_t)__popcll(__ballot(cur <= end));
-        uint32_t nFin = (uint32_t)__popcll(__ballot(wfin != 0u));
+        uint32_t nFin = (uint32_t)__popcll(__ballot(cur == kQFin));
         const uint32_t nEmp = 64u - nAct - nFin;
         bool idle = true;                                        // nothing was done in this round: the wave's tasks are finished
 
@@ -154,18 +192,19 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             const uint32_t k = ne < nR ? ne : nR;
             const uint32_t rk = rank_q(me);
             const bool take = cur > end && rk < k;
-            const uint32_t pos = take ? nR - 1u - rk : 0u;
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+            const uint32_t pos = nR - 1u - rk;
+            float4 r0, r1, r2, r3;                               // (read and used by the taking lanes only)
             if (take) { r0 = RD0[pos]; r1 = RD1[pos]; r2 = RD2[pos]; r3 = RD3[pos]; }
             uint32_t hcls = 0u;                                  // 1: onto HIT, 2: onto HITR
-            if (wfin != 0u) {
-                reinterpret_cast<uint2*>(slots + wslot * kQSlotF4 + 4)[0] = make_uint2(near_key, near_i);
-                hcls = (near_key != kQInfKey && (__float_as_uint(s_mat[near_i].w) & 3u) == 2u) ? 2u : 1u;
+            if (cur == kQFin) {
+                cur = 1u;                                        // (end is 0 already)
+                const uint32_t inst = near_i - gb16;
+                *reinterpret_cast<uint2*>(slot_bytes + wslot * kQSlotBytes + 64u) = make_uint2(near_key, inst);
+                hcls = (near_key != kQInfKey && (__float_as_uint(s_mat[inst].w) & 3u) == 2u) ? 2u : 1u;
             }
             const unsigned long long mh = __ballot(hcls == 1u), mr = __ballot(hcls == 2u);
             if (hcls != 0u) LH[hcls == 2u ? S - 1u - nHR - rank_q(mr) : nH + rank_q(mh)] = (uint8_t)wslot;
             nH += (uint32_t)__popcll(mh); nHR += (uint32_t)__popcll(mr);
-            wfin = 0u;
             if (take) {
                 // a begun walk as grid_walk_begin left it (spt_grid.h); the index steps follow from the direction's signs as there
                 wo = mk(r0.x, r0.y, r0.z); near_key = __float_as_uint(r0.w);
@@ -174,9 +213,9 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                 near_i = pk & 0xFFFFu; wslot = pk >> 16;
                 wtx = r2.x; wty = r2.y; wtz = r2.z; wci = __float_as_uint(r2.w);
                 wdx = r3.x; wdy = r3.y; wdz = r3.z;
-                wsx = !(wd.x > 0.0f) ? -1 : 1; wsy = !(wd.y > 0.0f) ? -stride_y : stride_y; wsz = !(wd.z > 0.0f) ? -stride_z : stride_z;
+                wsx = !(wd.x > 0.0f) ? -4 : 4; wsy = !(wd.y > 0.0f) ? -stride_y : stride_y; wsz = !(wd.z > 0.0f) ? -stride_z : stride_z;
                 const uint32_t h0 = __float_as_uint(r3.w);       // the start cell (never a border cell)
-                cur = h0 >> kGridCountBits; end = cur + (h0 & ((1u << kGridCountBits) - 1u));
+                cur = h0 & 0xFFFFu; end = h0 >> 16;
             }
             nR -= k;
             nAct += k; nFin = 0u;
@@ -223,34 +262,36 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             uint32_t thr = 0u;
             if (nAct + nFin > Q.drain) thr = nAct + nFin - Q.drain;           // finished lanes' = nFin + (nAct - act) >= drain
             if ((nR != 0u || (cap >= minb && nR < Q.drain)) && 64u - Q.drain > thr) thr = 64u - Q.drain;
-            uint32_t iters = run_batch ? Q.walk_iters : 0xFFFFFFFFu;
+            thr = uniq(thr);                                     // (wave-uniform by construction; the loop's exit test stays scalar)
+            uint32_t iters = uniq(run_batch ? Q.walk_iters : 0xFFFFFFFFu);
             for (;;) {
                 if (STATS) { ++st_iter; st_act += (uint32_t)__popcll(__ballot(cur <= end)); }
                 if (cur == end) {
                     // ---- STEP: all spheres of the cell are tested; leave it (spt_grid.h (3)) ----
                     const float m = __builtin_fminf(wtx, __builtin_fminf(wty, wtz));   // grid_walk_exit
                     const float near_t = __uint_as_float(near_key + kQEpsBias);    // 1e20 while nothing is hit
-                    uint32_t h = kGridBorder;
+                    uint32_t h = kQFin;
                     if (m < near_t) {                            // else: every cell up to the hit has been visited
                         grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, m);
-                        h = s_cells[wci];
+                        h = lds_u32(wci);                        // kQFin: the ray has left the table
                     }
-                    if (h != kGridBorder) { cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u)); }
-                    else { cur = 1u; end = 0u; wfin = 1u; }      // ... or the ray has left the table
+                    cur = h & 0xFFFFu; end = h >> 16;
                     if (STATS) st_step += 1;                     // (per lane; reduced at the end)
                 }
                 if (cur < end) {
                     // ---- TEST: the next sphere of the lane's cell ----
-                    const uint32_t ti = s_refs[cur];
-                    ++cur;
-                    const uint32_t key = sphere_key_q(s_geom[ti], wo, wd);
-                    // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
-                    const bool better = (key < near_key) | ((key == near_key) & (ti < near_i));
+                    const uint32_t ti = lds_u16(cur);
+                    cur += 2u;
+                    const uint32_t key = sphere_key_q(lds_f4(ti << 4), wo, wd);
+                    // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys --
+                    // (key, reference) pairs compared as 64-bit numbers, one instruction
+                    const bool better = (((unsigned long long)key << 32) | ti) < (((unsigned long long)near_key << 32) | near_i);
                     near_key = better ? key : near_key;
                     near_i = better ? ti : near_i;
                     if (STATS) st_test += 1;
                 }
-                if ((uint32_t)__popcll(__ballot(cur <= end)) <= thr || --iters == 0u) break;
+                asm volatile("s_sub_u32 %0, %0, 1" : "+s"(iters) :: "scc");
+                if (uniq((uint32_t)__popcll(__ballot(cur <= end))) <= thr || iters == 0u) break;
             }
             QSTAMP(0)
         }
@@ -522,7 +563,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             const GridParams& GB = *(const GridParams*)gp;
             bool ok = false;
             float t_ok = __builtin_inff();
-            uint32_t bkey = kQInfKey, bi = 0u;                   // index 0 with the inf key: never replaced by another inf key, never taken for a hit
+            uint32_t bkey = kQInfKey, bi = gb16;                 // (a reference: index + gb16) index 0 with the inf key: never taken for a hit
             if (has_ray) {
                 ok = grid_ray_ok(GB, o.x, o.y, o.z, d.x, d.y, d.z, t_ok);
                 if (!ok) t_ok = __builtin_inff();                // the exhaustive loop's answer needs no range
@@ -531,7 +572,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             }
             for (uint32_t k = 0; k < G.nalways; ++k) {           // ascending indices, strict '<' (smallpt.cpp:61)
                 const uint32_t i = s_refs[G.nrefs + k];
-                const float4 g = s_geom[i];
+                const float4 g = lds_f4(i << 4);
                 if (has_ray && ok) {
                     const uint32_t key = sphere_key_q(g, o, d);
                     if (key < bkey) { bkey = key; bi = i; }
@@ -544,12 +585,12 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                     const float4 g = s_geom[i];
                     if (has_ray && !ok) {
                         const uint32_t key = sphere_key_q(g, o, d);
-                        if (key < bkey) { bkey = key; bi = i; }
+                        if (key < bkey) { bkey = key; bi = i + gb16; }
                     }
                 }
                 if (has_ray && !ok) {
-                    reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(bkey, bi);
-                    requeue = (bkey != kQInfKey && (__float_as_uint(s_mat[bi].w) & 3u) == 2u) ? 2u : 1u;
+                    reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(bkey, bi - gb16);
+                    requeue = (bkey != kQInfKey && (__float_as_uint(s_mat[bi - gb16].w) & 3u) == 2u) ? 2u : 1u;
                 }
             }
             const bool begun = has_ray && ok;
@@ -560,8 +601,9 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                 const uint32_t pos = nR + rank_q(mb);
                 RD0[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(bkey));
                 RD1[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(bi | (slot << 16)));
-                RD2[pos] = make_float4(gw.tx, gw.ty, gw.tz, __uint_as_float(gw.ci));
-                RD3[pos] = make_float4(gw.dtx, gw.dty, gw.dtz, __uint_as_float(s_cells[gw.ci]));
+                const uint32_t cb = cells_off + 4u * gw.ci;
+                RD2[pos] = make_float4(gw.tx, gw.ty, gw.tz, __uint_as_float(cb));
+                RD3[pos] = make_float4(gw.dtx, gw.dty, gw.dtz, __uint_as_float(lds_u32(cb)));   // (the staged header)
             }
             nR += (uint32_t)__popcll(mb);
         }
@@ -608,8 +650,9 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 extern "C" size_t spt_gpool_lds_bytes(const spt::GridParams* G, uint32_t waves, uint32_t S, uint32_t R)
 {
     const size_t ngeom = G->n ? G->n : 1u;
-    const size_t tables = ((ngeom * 16u + (size_t)G->ncells * 4u + (((size_t)G->nrefs + G->nalways + 2u) / 2u) * 4u + 15u) & ~(size_t)15u) + ngeom * 16u;
-    return tables + (size_t)waves * ((size_t)R * 64u + 2u * (size_t)S);
+    const size_t geom_off = (((size_t)G->nrefs + G->nalways + 1u) * 2u + 15u) & ~(size_t)15u;
+    const size_t mat_off = (geom_off + ngeom * 16u + (size_t)G->ncells * 4u + 15u) & ~(size_t)15u;
+    return mat_off + ngeom * 16u + (size_t)waves * ((size_t)R * 64u + 2u * (size_t)S);
 }
 extern "C" size_t spt_gpool_slot_floats(uint32_t blocks, uint32_t waves, uint32_t S) { return (size_t)blocks * waves * S * (spt::kQSlotF4 * 4u); }
 extern "C" size_t spt_gpool_stack_floats(uint32_t blocks, uint32_t waves, uint32_t S) { return (size_t)blocks * waves * S * (3u * spt::kQStackF4 * 4u); }
@@ -618,11 +661,16 @@ extern "C" hipError_t spt_gpool_launch(const spt::KParams* K, const spt::GridPar
                                        const uint32_t* d_always, const spt::QParams* Q, uint32_t blocks, uint32_t threads, int stats, hipStream_t stream)
 {
     if (threads == 0 || threads > (uint32_t)spt::kQBlock || (threads & 63u)) return hipErrorInvalidValue;
-    if (Q->S == 0 || Q->S > 256u || (Q->S & 15u) || (Q->R & 3u) || Q->R == 0 || Q->R > 0xFFFFu || Q->drain == 0 || Q->drain > 64u || G->n > 0xFFFFu) return hipErrorInvalidValue;
+    if (Q->S == 0 || Q->S > 256u || (Q->S & 15u) || (Q->R & 3u) || Q->R == 0 || Q->R > 0xFFFFu || Q->drain == 0 || Q->drain > 64u || G->nrefs >= 0x7FFEu) return hipErrorInvalidValue;
+    if ((((size_t)G->nrefs + G->nalways + 1u) * 2u + 15u) / 16u + G->n > 0xFFFFu) return hipErrorInvalidValue;   // references (index + gb16) are 16 bits
     const size_t lds = spt_gpool_lds_bytes(G, threads / 64u, Q->S, Q->R);
     if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
     const void* fn = stats ? reinterpret_cast<const void*>(&spt::gpoolkernel<true>) : reinterpret_cast<const void*>(&spt::gpoolkernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncAttributes fa{};
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    if (e != hipSuccess) return e;
+    if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;   // the kernel's LDS addressing assumes its dynamic LDS starts at 0
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (stats) hipLaunchKernelGGL(spt::gpoolkernel<true>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, *Q);
     else hipLaunchKernelGGL(spt::gpoolkernel<false>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, *Q);

@@ -19,6 +19,11 @@ extern "C" {
  * 1 + q, a wave leaves its walk phase when 16 x walking lanes < q x waiting lanes (0 = default q = 16), bits 31:24 = grid cells per sphere
  * (read by spt_set_scene; 0 = default 4).  Results never depend on these. */
 int  spt_set_tuning(spt_ctx* ctx, uint32_t blocks_per_cu, uint32_t variant);
+/* Large sphere tables through the uniform grid: lane_owned = 1 keeps the kernel whose lanes own their path (spt_grid.hip) where the
+ * default -- wave-private path pools with walker lanes, spt_gpool.hip -- would run; slots / ready / drain / min_batch / walk_iters set
+ * the pool geometry (0 = default 192 slots per wave, up to 96 begun walks per wave in LDS, an exchange per 24 finished walker lanes,
+ * batches of >= 32 while the walkers starve, 4 walk iterations behind a batch's loads).  Results never depend on these. */
+int  spt_set_grid_pools(spt_ctx* ctx, int lane_owned, uint32_t slots, uint32_t ready, uint32_t drain, uint32_t min_batch, uint32_t walk_iters);
 /* Pool kernel: bit 13 = hand the task chunks out in their static order (no cost-ordered dispatch, spt_kernel.h KParams::chunk_order; the
  * grid kernel reads bits 15:13 as its workgroup size). */
 /* Pool kernel, cost-ordered dispatch: copies the chunk order that the last pool launch left for the next launch of the same view
@@ -34,7 +39,8 @@ int  spt_diag(spt_ctx* ctx, unsigned long long* out24);
  * cannot hang the GPU box. */
 int  spt_set_watchdog(spt_ctx* ctx, double seconds);
 /* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip),
- * 2 = mesh kernel (spt_mesh.hip, triangles), 3 = mesh kernel over a sphere hierarchy (SPT_ACCEL_BVH), 4 = grid kernel (spt_grid.hip).
+ * 2 = mesh kernel (spt_mesh.hip, triangles), 3 = mesh kernel over a sphere hierarchy (SPT_ACCEL_BVH), 4 = grid kernel with lane-owned
+ * paths (spt_grid.hip), 5 = grid kernel with wave-private path pools (spt_gpool.hip).
  * After a grid launch spt_diag returns out24[0..1] = cell steps / sphere tests of the walks, [2..3] = wave iterations of either kind,
  * [4] = rays that took the exhaustive loop, [5] = rounds, [7] = shaded hits.
  * After a pool launch spt_diag returns out24[0..2] = batches per class (GEN, DIFF, REFR), [3..5] = lanes per class. */

@@ -101,6 +101,8 @@ class Renderer:
         st = self._state
         if st["tuning"] is not None:
             other.set_tuning(*st["tuning"])
+        if st.get("grid_pools") is not None:
+            other.set_grid_pools(*st["grid_pools"])
         if st["watchdog"] is not None:
             other.set_watchdog(st["watchdog"])
         if st["sphere_accel"] is not None:
@@ -170,6 +172,13 @@ class Renderer:
     def set_tuning(self, blocks_per_cu=0, variant=0):
         self._check(self._lib.spt_set_tuning(self._h, blocks_per_cu, variant))
         self._state["tuning"] = (int(blocks_per_cu), int(variant))
+        self._state_version += 1
+
+    def set_grid_pools(self, lane_owned=False, slots=0, ready=0, drain=0, min_batch=0, walk_iters=0):
+        """Large sphere tables (csrc/spt_internal.h spt_set_grid_pools): keep the lane-owned grid kernel, or set the pool geometry of the
+        default one (0 = default).  Results never depend on it."""
+        self._check(self._lib.spt_set_grid_pools(self._h, int(bool(lane_owned)), slots, ready, drain, min_batch, walk_iters))
+        self._state["grid_pools"] = (bool(lane_owned), slots, ready, drain, min_batch, walk_iters)
         self._state_version += 1
 
     def render(self, w, h, samps_per_cell, seed=0, normalise=False, camera=None):

@@ -1,7 +1,7 @@
 """Compiler-reported resources of EVERY product kernel (cross-compiled for gfx950 here, no GPU needed): path state stays in
 registers -- no scalar or vector spills, no scratch -- and the occupancy the launch geometry counts on is available.  Reads the
--Rpass-analysis=kernel-resource-usage remarks of the four device translation units.  Instrumented builds (megakernel DIAG,
-gridkernel STATS: selected by tuning bit 8 only, never timed as the product) are exempt from the spill rule but must not use scratch."""
+-Rpass-analysis=kernel-resource-usage remarks of the five device translation units.  Instrumented builds (megakernel DIAG,
+gridkernel / gpoolkernel STATS: selected by tuning bit 8 only, never timed as the product) are exempt from the spill rule but must not use scratch."""
 import os
 import re
 import subprocess
@@ -44,6 +44,7 @@ def test_pool_kernels_do_not_spill(tmp_path):
     ("spt_kernel.hip", ("megakernel", "finalize", "accumulate"), 4),     # 4 waves/SIMD: four 256-thread workgroups per CU
     ("spt_mesh.hip", ("meshkernel", "trace_rays"), 4),
     ("spt_grid.hip", ("gridkernel",), 4),                                # one 1024-thread workgroup per CU = 4 waves/SIMD
+    ("spt_gpool.hip", ("gpoolkernel",), 4),                              # the same geometry
 ])
 def test_product_kernels_do_not_spill(unit, expect, min_occupancy, tmp_path):
     kernels = _resources(unit, tmp_path)
@@ -51,7 +52,7 @@ def test_product_kernels_do_not_spill(unit, expect, min_occupancy, tmp_path):
         assert any(stem in k for k in kernels), (stem, sorted(kernels))
     for k, r in kernels.items():
         # Itanium mangling of the template arguments: megakernel<MAT_LDS, GUARD, DIAG, BIGN, BLOCK> -> ...ILb?ELb?ELb1E...; gridkernel<STATS> -> ILb1E
-        instrumented = ("megakernel" in k and re.search(r"megakernelILb[01]ELb[01]ELb1E", k)) or ("gridkernel" in k and "gridkernelILb1E" in k)
+        instrumented = ("megakernel" in k and re.search(r"megakernelILb[01]ELb[01]ELb1E", k)) or ("gridkernel" in k and "gridkernelILb1E" in k) or "gpoolkernelILb1E" in k
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (k, r)
         if not instrumented:
             assert r["SGPRs Spill"] == 0, (k, r)

@@ -96,8 +96,10 @@ def test_sphere_grid_walk_equals_exhaustive_on_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle):
-    """Default mode: tables above 24 spheres run the grid kernel; image and bounce count equal the oracle's exhaustive loop."""
+@pytest.mark.parametrize("lane_owned", [False, True], ids=["path pools", "lane-owned"])
+def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle, lane_owned):
+    """Default mode: tables above 24 spheres run a grid kernel -- wave-private path pools with walker lanes (spt_gpool.hip, the default)
+    or lanes that own their path (spt_grid.hip) --; image and bounce count equal the oracle's exhaustive loop."""
     scenes = [("cluster 25", _cluster_scene(pkg, 25, 5)), ("cluster 100", _cluster_scene(pkg, 100, 6)), ("cluster 600", _cluster_scene(pkg, 600, 7)),
               ("open 257", _cluster_scene(pkg, 257, 8, huge=False)), ("config 5", pkg.random_spheres(1024, 1024)), ("random 4096", pkg.random_spheres(4096, 7)),
               ("identical 50", pkg.make_spheres([(1.0, (50, 40, 80), (1, 1, 1), (.5, .5, .5), 0)] * 50)),
@@ -106,34 +108,52 @@ def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle):
               ("cluster 4096", _cluster_scene(pkg, 4096, 9)),
               # sphere records beyond one CU's LDS: the hierarchy by default
               ("random 12000", pkg.random_spheres(12000, 11))]
-    expect = {"cluster 4096": "sbvh", "random 12000": "sbvh"}
-    for name, sc in scenes:
-        w, h, samps, seed = (40, 30, 2, 3) if len(sc) < 600 else (32, 20, 1, 4)
+    name_of = "grid" if lane_owned else "gpool"
+    # 4096 sphere records + their grid leave no room for the pools' begun walks: the lane-owned kernel keeps such tables
+    expect = {"cluster 4096": "sbvh", "random 12000": "sbvh", "random 4096": "grid"}
+    try:
+        renderer.set_grid_pools(lane_owned=lane_owned)
+        for name, sc in scenes:
+            w, h, samps, seed = (40, 30, 2, 3) if len(sc) < 600 else (32, 20, 1, 4)
+            renderer.set_scene(sc)
+            img, st = renderer.render(w, h, samps, seed=seed)
+            assert renderer.last_kernel() == expect.get(name, name_of), name
+            ref, rst = oracle.render(sc, w, h, samps, seed=seed)
+            assert np.array_equal(img, ref), (name, int((img != ref).any(axis=-1).sum()))
+            assert st["bounces"] == rst["bounces"] and st["max_depth_kills"] == rst["max_depth_kills"], name
+            for cam in (pkg.pinhole_camera(org=(50, 45, 160), vz=(0, 0, -1)),               # the viewer's camera, inside the scene
+                        pkg.pinhole_camera(org=(50, 45, 2000), vz=(0, 0, -1))):             # far outside: rays beyond the grid's error bound take the exhaustive loop
+                img, st = renderer.render(w, h, samps, seed=seed + 1, camera=cam)
+                ref, rst = oracle.render(sc, w, h, samps, seed=seed + 1, camera=cam)
+                assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"], (name, "pinhole")
+        # several D9 sample blocks per cell, a ragged size and the normalised output
+        sc = pkg.random_spheres(1024, 1024)
         renderer.set_scene(sc)
-        img, st = renderer.render(w, h, samps, seed=seed)
-        assert renderer.last_kernel() == expect.get(name, "grid"), name
-        ref, rst = oracle.render(sc, w, h, samps, seed=seed)
-        assert np.array_equal(img, ref), (name, int((img != ref).any(axis=-1).sum()))
-        assert st["bounces"] == rst["bounces"] and st["max_depth_kills"] == rst["max_depth_kills"], name
-        for cam in (pkg.pinhole_camera(org=(50, 45, 160), vz=(0, 0, -1)),               # the viewer's camera, inside the scene
-                    pkg.pinhole_camera(org=(50, 45, 2000), vz=(0, 0, -1))):             # far outside: rays beyond the grid's error bound take the exhaustive loop
-            img, st = renderer.render(w, h, samps, seed=seed + 1, camera=cam)
-            ref, rst = oracle.render(sc, w, h, samps, seed=seed + 1, camera=cam)
-            assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"], (name, "pinhole")
-    # several D9 sample blocks per cell, a ragged size and the normalised output
-    sc = pkg.random_spheres(1024, 1024)
-    renderer.set_scene(sc)
-    img, st = renderer.render(9, 7, 70, seed=11, normalise=True)
-    ref, rst = oracle.render(sc, 9, 7, 70, seed=11, normalise=True)
-    assert renderer.last_kernel() == "grid" and np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
-    # the walk-phase policy (when a wave leaves its walk phase) and the resolution never change the image
-    for variant in (1 << 16, 5 << 16, 65 << 16, (1 << 16) | (3 << 24), 40 << 24):
-        renderer.set_tuning(0, variant)
-        renderer.set_scene(sc)
-        img2, st2 = renderer.render(32, 20, 1, seed=4)
+        img, st = renderer.render(9, 7, 70, seed=11, normalise=True)
+        ref, rst = oracle.render(sc, 9, 7, 70, seed=11, normalise=True)
+        assert renderer.last_kernel() == name_of and np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
         ref2, rst2 = oracle.render(sc, 32, 20, 1, seed=4)
-        assert np.array_equal(img2, ref2) and st2["bounces"] == rst2["bounces"], hex(variant)
-    renderer.set_tuning(0, 0)
+        if lane_owned:
+            # the walk-phase policy (when a wave leaves its walk phase) and the resolution never change the image
+            for variant in (1 << 16, 5 << 16, 65 << 16, (1 << 16) | (3 << 24), 40 << 24):
+                renderer.set_tuning(0, variant)
+                renderer.set_scene(sc)
+                img2, st2 = renderer.render(32, 20, 1, seed=4)
+                assert np.array_equal(img2, ref2) and st2["bounces"] == rst2["bounces"], hex(variant)
+        else:
+            # the pool geometry (slots and begun walks per wave, when walkers are exchanged, the smallest batch), the workgroup size and
+            # the resolution never change the image
+            for geom, variant in (((64, 48, 1, 1, 1), 0), ((256, 96, 64, 64, 16), 0), ((192, 52, 8, 16, 2), 3 << 24), ((0, 0, 0, 0, 0), 3 << 13), ((128, 64, 40, 8, 0), 10 << 24),
+                                  ((0, 0, 0, 0, 0), 40 << 24)):          # 40 cells per sphere: more references than the walkers' 16-bit addresses reach -> lane-owned kernel
+                renderer.set_grid_pools(False, *geom)
+                renderer.set_tuning(0, variant)
+                renderer.set_scene(sc)
+                img2, st2 = renderer.render(32, 20, 1, seed=4)
+                assert renderer.last_kernel() == ("grid" if variant == 40 << 24 else "gpool"), (geom, hex(variant))
+                assert np.array_equal(img2, ref2) and st2["bounces"] == rst2["bounces"], (geom, hex(variant))
+    finally:
+        renderer.set_tuning(0, 0)
+        renderer.set_grid_pools()
     renderer.set_scene(pkg.cornell9())
     renderer.render(8, 8, 1)
     assert renderer.last_kernel() == "pool"

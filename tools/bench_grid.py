@@ -1,6 +1,7 @@
 """Config 5 (1024 spheres, 1024x768) and larger tables on the grid kernel (spt_grid.hip): kernel time, Msamples/s, walk statistics
 (cell steps / sphere tests per ray, lane utilisation of both loop bodies), oracle rows for parity, and A/B over the tuning knobs.
-usage: bench_grid.py [samps] [variant,variant,...]   (variants: hex words for spt_set_tuning, e.g. 0x0,0x50000,0x10000000)"""
+usage: bench_grid.py [samps] [variant,variant,...] [--lane-owned] [--stats] [--nocheck] [--big]
+(variants: hex words for spt_set_tuning, e.g. 0x0,0x50000,0x10000000; --lane-owned: spt_grid.hip instead of the path pools of spt_gpool.hip)"""
 import json
 import os
 import sys
@@ -11,12 +12,14 @@ import optix_test_smallpt_amd as pkg
 import oracle_binding as orc
 
 samps = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-variants = [(int(v.split(":")[0], 16), int(v.split(":")[1]) if ":" in v else 0) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [(0, 0)]   # variant[:blocks per CU]
+variants = [(int(v.split(":")[0], 16), int(v.split(":")[1]) if ":" in v else 0) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else [(0, 0)]   # variant[:blocks per CU]
 scenes = [("config 5: 1024 spheres", pkg.random_spheres(1024, 1024), [100, 500])]
 if "--big" in sys.argv:
     scenes.append(("4096 spheres", pkg.random_spheres(4096, 7), [300]))
 r = pkg.Renderer(0)
 r.set_watchdog(120.0)
+if "--lane-owned" in sys.argv:
+    r.set_grid_pools(lane_owned=True)
 rows = []
 w, h = 1024, 768
 for name, sc, check_rows in scenes:

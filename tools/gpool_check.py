@@ -26,12 +26,12 @@ if bad:
     sys.exit(1)
 sc = pkg.random_spheres(1024, 1024)
 refs = {row: orc.render(sc, 1024, 768, 64, seed=0, normalise=True, row_begin=row, row_count=1)[0] for row in (100, 500)}
-for variant in (0x0, 0x1000000):
-    r.set_tuning(0, variant)
+for variant in (0, 1):
+    r.set_grid_pools(lane_owned=bool(variant))
     r.set_scene(sc)
     best = None
     for _ in range(3):
         img, st = r.render(1024, 768, 64, seed=0, normalise=True)
         best = st if best is None or st["kernel_ms"] < best["kernel_ms"] else best
     exact = all(bool(np.array_equal(img[row:row + 1], ref)) for row, ref in refs.items())
-    print(f"config 5 at 256 spp, variant {variant:#x}: kernel={r.last_kernel()} kernel_ms={best['kernel_ms']:.2f} Msamples/s={best['samples'] / best['kernel_ms'] / 1e3:.1f} bit_exact={exact}", flush=True)
+    print(f"config 5 at 256 spp, lane_owned={variant}: kernel={r.last_kernel()} kernel_ms={best['kernel_ms']:.2f} Msamples/s={best['samples'] / best['kernel_ms'] / 1e3:.1f} bit_exact={exact}", flush=True)

@@ -68,6 +68,22 @@ __global__ __launch_bounds__(256) void k(float* out, float a0, float b0, unsigne
                 if (OP == 48) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(y[i]) : "v"(u0));
                 if (OP == 49) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(y[i]), "v"(u0) : "vcc");
                 if (OP == 50) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x[i]) : "v"(b));
+                if (OP == 51) asm volatile("v_cmp_lt_u64_e32 vcc, %0, %1" : : "v"(z[i & 3]), "v"(z[(i + 1) & 3]) : "vcc");
+                if (OP == 52) asm volatile("v_bfe_u32 %0, %0, 3, 16" : "+v"(y[i]));
+                if (OP == 53) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 55) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(y[i]) : "v"(u0) : "vcc");
+                if (OP == 56) asm volatile("v_readfirstlane_b32 s22, %0" : : "v"(y[i]) : "s22");
+                if (OP == 57) asm volatile("v_mbcnt_lo_u32_b32 %0, s20, %0" : "+v"(y[i]));
+                if (OP == 58) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(y[i]) : "v"(u0));
+                if (OP == 59) asm volatile("v_cmp_eq_u32_e64 s[22:23], %0, %1" : : "v"(y[i]), "v"(u0) : "s22", "s23");
+                if (OP == 60) asm volatile("v_add_f32_e64 %0, |%0|, %1" : "+v"(x[i]) : "v"(b));
+                if (OP == 61) asm volatile("v_mul_f32_e64 %0, -%0, %1" : "+v"(x[i]) : "v"(b));
+                if (OP == 62) asm volatile("v_cndmask_b32_e64 %0, 0, %1, s[20:21]" : "+v"(x[i]) : "v"(b) : );
+                if (OP == 63) asm volatile("v_add_u32 %0, 0x38d1b718, %0" : "+v"(y[i]));
+                if (OP == 64) asm volatile("v_add_u32 %0, 5, %0" : "+v"(y[i]));
+                if (OP == 65) asm volatile("v_sub_f32_e64 %0, %0, %1" : "+v"(x[i]) : "v"(b));
+                if (OP == 66) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(y[i]));
+                if (OP == 68) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1\n\tv_add_f32 %2, %2, %3" : "+v"(y[i]) : "v"(u0), "v"(x[i]), "v"(b) : "vcc");
                 if (OP == 8) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(y[i]) : "v"(u0));
                 if (OP == 9) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[i]), "v"(b) : "vcc");
                 if (OP == 10) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(y[i]) : "v"(u0));
@@ -136,6 +152,11 @@ int main()
         run<40>("v_mul_hi_u32", w, d); run<41>("v_ldexp_f32", w, d); run<42>("v_rsq_f32", w, d);
         run<44>("v_mad_u64_u32", w, d); run<45>("v_cvt_i32_f32", w, d); run<46>("v_add3_u32", w, d); run<47>("v_min_u32", w, d);
         run<48>("v_and_or_b32", w, d); run<49>("v_cmp_lt_u32", w, d); run<50>("v_fmac_f32", w, d);
+        run<51>("v_cmp_lt_u64", w, d); run<52>("v_bfe_u32", w, d); run<53>("v_lshl_or_b32", w, d); run<55>("v_add_co_u32", w, d);
+        run<56>("v_readfirstlane", w, d); run<57>("v_mbcnt_lo", w, d); run<58>("v_min3_u32", w, d); run<59>("v_cmp_eq_u32_e64", w, d);
+        run<60>("v_add_f32 |abs|", w, d); run<61>("v_mul_f32 -neg", w, d); run<62>("v_cndmask 0,v,s", w, d); run<63>("v_add_u32 literal", w, d);
+        run<64>("v_add_u32 inline5", w, d); run<65>("v_sub_f32_e64", w, d); run<66>("v_mov_dpp row_shr", w, d);
+        run<68>("cmp_u32+add_f32 (x2)", w, d);
         printf("\n");
     }
     return 0;
