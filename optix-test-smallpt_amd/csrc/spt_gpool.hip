@@ -33,6 +33,7 @@ constexpr uint32_t kQEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) 
 constexpr uint32_t kQInfKey = 0x60AD78ECu - kQEpsBias;           // key of 1e20f (maths.h:16)
 constexpr uint32_t kQSlotBytes = 96;                             // = 16 kQSlotF4
 constexpr int kQSlotF4 = 6;                                      // float4 per slot in global memory
+constexpr uint32_t kQFew = 4u;                                   // a batch that leaves at most this many rays answers them with the whole wave
 constexpr uint32_t kQFin = 0xFFFFu;                              // staged header of a border cell / the walker's cur when its walk has ended
 constexpr int kQStackF4 = 4;                                     // one pending child = one 64-byte line
 
@@ -73,6 +74,27 @@ __device__ __forceinline__ uint32_t lds_u16(uint32_t) { return 0u; }
 __device__ __forceinline__ uint32_t lds_u32(uint32_t) { return 0u; }
 __device__ __forceinline__ float4 lds_f4(uint32_t) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 #endif
+
+// The exhaustive loop of smallpt.cpp:54-70 for ONE ray by the whole wave: lane l tests spheres l, l + 64, ... in ascending order with
+// strict '<' (the lowest index among a lane's equal keys), then the wave takes the lexicographic minimum of (key, index) -- the key the
+// sequential loop ends with and, among the spheres that produce it, the lowest index (:61).  o / d are wave-uniform.  Used where a wave
+// has only a few rays to answer (the end of a launch, a lone 4096-bounce path in a closed white ball): n / 64 tests per lane instead
+// of the always-tested list and a walk in one lane.
+__device__ __forceinline__ void wave_closest_sphere(const float4* geom, uint32_t n, f3 o, f3 d, uint32_t lane, uint32_t& key_out, uint32_t& idx_out)
+{
+    uint32_t bk = kQInfKey, bi = 0u;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t key = sphere_key_q(geom[i], o, d);
+        if (key < bk) { bk = key; bi = i; }
+    }
+#pragma unroll 1
+    for (int off = 32; off > 0; off >>= 1) {                     // (rolled: this is the rare path, the main loop keeps its registers)
+        const uint32_t k2 = (uint32_t)__shfl_xor((int)bk, off), i2 = (uint32_t)__shfl_xor((int)bi, off);
+        const bool better = (k2 < bk) | ((k2 == bk) & (i2 < bi));
+        bk = better ? k2 : bk; bi = better ? i2 : bi;
+    }
+    key_out = bk; idx_out = bk == kQInfKey ? 0u : bi;            // (a miss keeps index 0 like the sequential loop)
+}
 
 // packed word of a slot (Q1.w): [11:0] depth, [14:12] branch bits (D7), [15] weight-may-be-non-finite flag, [31:30] pending
 // transmitted children of the slot's current sample
@@ -153,11 +175,12 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
     bool timed_out = false;
     uint32_t n_loop = 0;
     // statistics (STATS build)
-    unsigned long long st_iter = 0, st_act = 0, st_exch = 0, st_fin = 0, st_test = 0, st_step = 0, st_redo = 0;
-    unsigned long long st_bat[3] = {0, 0, 0}, st_lan[3] = {0, 0, 0};
-    unsigned long long t_dry = 0;                                // when this wave found the task queue empty
-    unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = 0;           // wave time: walk, exchange, generation batches, shading batches
-#define QSTAMP(i) if (STATS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
+    // (32-bit per wave -- a launch of the instrumented build lasts less than 2^32 clocks --: as 64-bit scalars they cost spill lanes and scratch)
+    uint32_t st_iter = 0, st_act = 0, st_exch = 0, st_redo = 0;
+    uint32_t st_test = 0, st_step = 0;                           // per lane
+    uint32_t st_bat[3] = {0, 0, 0}, st_lan[3] = {0, 0, 0};
+    uint32_t ph[4] = {0, 0, 0, 0}, ph_t = 0;                     // wave time: walk, exchange, generation batches, shading batches
+#define QSTAMP(i) if (STATS) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph[i] += t_ - ph_t; ph_t = t_; }
 
     // ---- the lane's walk (registers): the fields of a GridWalk (spt_grid.h), the ray, the nearest (key, index) so far and the references
     // [cur, end) of the current cell that are still to test (byte addresses in s_refs).  cur == end: the cell is exhausted, the lane
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
     int32_t stride_y = 4 * G.stride_y, stride_z = 4 * G.stride_z;      // (of byte addresses)
     asm volatile("" : "+v"(stride_y), "+v"(stride_z));
 
-    if (STATS) ph_t = __builtin_amdgcn_s_memtime();
+    if (STATS) ph_t = (uint32_t)__builtin_amdgcn_s_memtime();
     for (;;) {
         if ((++n_loop & 63u) == 0u && K.watchdog_ticks != 0ull && __builtin_amdgcn_s_memtime() - t_start > K.watchdog_ticks) { timed_out = true; break; }
         uint32_t nAct = (uint32_t)__popcll(__ballot(cur <= end));
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 
         if ((nFin != 0u && (nFin >= Q.drain || nAct == 0u)) || (nR != 0u && nEmp + nFin != 0u && (nEmp + nFin >= Q.drain || nAct == 0u))) {
             // =============== exchange: finished walkers hand their hits over, empty lanes take begun walks ===============
-            if (STATS) { ++st_exch; st_fin += nFin; }
+            if (STATS) ++st_exch;
             idle = false;
             // (finished lanes are empty lanes already -- cur > end --, so the begun walks can be fetched before the hits are handed over:
             // the LDS reads of both halves are in flight together)
@@ -348,9 +371,9 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                         uint32_t nb = 0;
                         if ((int)lane == leader) nb = atomicAdd(K.queue, 64u);
                         base_new = uniq(__shfl(nb, leader));
-                        if (base_new >= K.ntasks) { queue_empty = true; if (STATS) t_dry = __builtin_amdgcn_s_memtime(); }
+                        if (base_new >= K.ntasks) { queue_empty = true; }
                     } else {
-                        base_new = K.ntasks;                     // nothing left: ids >= ntasks mean "no task"
+                        base_new = 0xFFFFFF00u;                  // nothing left: a queue position that stands for no task (deal_task)
                     }
                     chunk_next = base_new + (cntn - avail);
                     chunk_end = base_new + 64u;
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                     chunk_next += cntn;
                 }
                 if (need_task) {
-                    const uint32_t nt = rk < avail ? base_old + rk : base_new + (rk - avail);
+                    const uint32_t nt = deal_task(rk < avail ? base_old + rk : base_new + (rk - avail), K.ntasks);   // (spt_device.h: a pixel's blocks go to different waves)
                     if (nt < K.ntasks) {
                         task1 = nt + 1u; gen = true;
                         snext = (nt & ((1u << K.nb_log2) - 1u)) * K.sb;
@@ -439,13 +462,25 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             const bool redo = valid && __uint_as_float(hkey + kQEpsBias) > q0.w;
             const unsigned long long mredo = __ballot(redo);
             if (mredo != 0ull) {
-                if (STATS) st_redo += (unsigned long long)__popcll(mredo);
+                if (STATS) st_redo += (uint32_t)__popcll(mredo);
                 if (redo) { hkey = kQInfKey; inst = 0u; }
-                for (uint32_t i = 0; i < G.n; ++i) {
-                    const float4 g = s_geom[i];
-                    if (redo) {
-                        const uint32_t key = sphere_key_q(g, ro, din);
-                        if (key < hkey) { hkey = key; inst = i; }
+                if ((uint32_t)__popcll(mredo) <= 32u) {          // ray by ray with the whole wave (wave_closest_sphere)
+                    unsigned long long todo = mredo;
+                    while (todo != 0ull) {
+                        const int rl = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        const f3 wro = mk(__shfl(ro.x, rl), __shfl(ro.y, rl), __shfl(ro.z, rl)), wrd = mk(__shfl(din.x, rl), __shfl(din.y, rl), __shfl(din.z, rl));
+                        uint32_t kk, ii;
+                        wave_closest_sphere(s_geom, G.n, wro, wrd, lane, kk, ii);
+                        if ((int)lane == rl) { hkey = kk; inst = ii; }
+                    }
+                } else {
+                    for (uint32_t i = 0; i < G.n; ++i) {
+                        const float4 g = s_geom[i];
+                        if (redo) {
+                            const uint32_t key = sphere_key_q(g, ro, din);
+                            if (key < hkey) { hkey = key; inst = i; }
+                        }
                     }
                 }
                 if (redo && hkey != kQInfKey) {
@@ -564,28 +599,47 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             bool ok = false;
             float t_ok = __builtin_inff();
             uint32_t bkey = kQInfKey, bi = gb16;                 // (a reference: index + gb16) index 0 with the inf key: never taken for a hit
+            // A batch that produced only a few rays (kQFew: the end of a launch; one roulette-immune path -- colour (1,1,1) mirror or glass --
+            // bouncing in a closed ball up to the depth cap) does not walk: the whole wave answers each ray with the exhaustive loop.
+            const unsigned long long mray = __ballot(has_ray);
+            const bool few = (uint32_t)__popcll(mray) <= kQFew;
             if (has_ray) {
-                ok = grid_ray_ok(GB, o.x, o.y, o.z, d.x, d.y, d.z, t_ok);
+                ok = grid_ray_ok(GB, o.x, o.y, o.z, d.x, d.y, d.z, t_ok) && !few;
                 if (!ok) t_ok = __builtin_inff();                // the exhaustive loop's answer needs no range
                 sq[0] = make_float4(o.x, o.y, o.z, t_ok);
                 sq[1] = make_float4(d.x, d.y, d.z, __uint_as_float(pack_q(depth, branchf, sp)));
             }
-            for (uint32_t k = 0; k < G.nalways; ++k) {           // ascending indices, strict '<' (smallpt.cpp:61)
-                const uint32_t i = s_refs[G.nrefs + k];
-                const float4 g = lds_f4(i << 4);
-                if (has_ray && ok) {
-                    const uint32_t key = sphere_key_q(g, o, d);
-                    if (key < bkey) { bkey = key; bi = i; }
+            if (!few) {
+                for (uint32_t k = 0; k < G.nalways; ++k) {       // ascending indices, strict '<' (smallpt.cpp:61)
+                    const uint32_t i = s_refs[G.nrefs + k];
+                    const float4 g = lds_f4(i << 4);
+                    if (has_ray && ok) {
+                        const uint32_t key = sphere_key_q(g, o, d);
+                        if (key < bkey) { bkey = key; bi = i; }
+                    }
                 }
             }
-            const unsigned long long bad = __ballot(has_ray && !ok);
+            unsigned long long bad = __ballot(has_ray && !ok);
             if (bad != 0ull) {                                   // spt_grid.h (4): the exhaustive loop of smallpt.cpp:54-70, in place
-                if (STATS) st_redo += (unsigned long long)__popcll(bad);
-                for (uint32_t i = 0; i < G.n; ++i) {
-                    const float4 g = s_geom[i];
-                    if (has_ray && !ok) {
-                        const uint32_t key = sphere_key_q(g, o, d);
-                        if (key < bkey) { bkey = key; bi = i + gb16; }
+                if (STATS) st_redo += (uint32_t)__popcll(bad);
+                if ((uint32_t)__popcll(bad) <= 32u) {
+                    // ... ray by ray with the whole wave (wave_closest_sphere)
+                    while (bad != 0ull) {
+                        const int rl = __ffsll((long long)bad) - 1;
+                        bad &= bad - 1ull;
+                        const f3 ro = mk(__shfl(o.x, rl), __shfl(o.y, rl), __shfl(o.z, rl)), rd = mk(__shfl(d.x, rl), __shfl(d.y, rl), __shfl(d.z, rl));
+                        uint32_t kk, ii;
+                        wave_closest_sphere(s_geom, G.n, ro, rd, lane, kk, ii);
+                        if ((int)lane == rl) { bkey = kk; bi = ii + gb16; }
+                    }
+                } else {
+                    // ... or every lane its own ray when most of the wave needs it
+                    for (uint32_t i = 0; i < G.n; ++i) {
+                        const float4 g = s_geom[i];
+                        if (has_ray && !ok) {
+                            const uint32_t key = sphere_key_q(g, o, d);
+                            if (key < bkey) { bkey = key; bi = i + gb16; }
+                        }
                     }
                 }
                 if (has_ray && !ok) {
@@ -623,23 +677,26 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
 #undef QSTAMP
 
     // stats: wave reduction then one atomic per wave
-    unsigned long long nk = nkill, ns = st_step, nt = st_test;
+    unsigned long long nk = nkill, ns = st_step, nt = st_test;   // (64-bit from here: sums over the wave)
     for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off); if (STATS) { ns += __shfl_down(ns, off); nt += __shfl_down(nt, off); } }
+    // (the counters' address is read from the kernel-argument segment here: kept in scalar registers across the main loop it costs spill lanes)
+    typedef const __attribute__((address_space(4))) KParams* KArgsE;
+    KArgsE ke = (KArgsE)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ke));
+    unsigned long long* const ctr = ke->counters;
     if (lane == 0) {
-        atomicAdd(&K.counters[0], nbounce);
-        if (nk) atomicAdd(&K.counters[1], nk);
-        if (timed_out) atomicAdd(&K.counters[8], 1ull);
+        atomicAdd(&ctr[0], nbounce);
+        if (nk) atomicAdd(&ctr[1], nk);
+        if (timed_out) atomicAdd(&ctr[8], 1ull);
         if (STATS) {
-            atomicAdd(&K.counters[2], ns); atomicAdd(&K.counters[3], nt);
-            atomicAdd(&K.counters[4], st_iter); atomicAdd(&K.counters[5], st_act);
-            atomicAdd(&K.counters[6], st_redo); atomicAdd(&K.counters[7], st_exch);
-            atomicAdd(&K.counters[9], st_fin);
-            for (int i = 0; i < 3; ++i) { atomicAdd(&K.counters[10 + i], st_bat[i]); atomicAdd(&K.counters[13 + i], st_lan[i]); }
-            for (int i = 0; i < 4; ++i) atomicAdd(&K.counters[16 + i], ph[i]);
+            atomicAdd(&ctr[2], ns); atomicAdd(&ctr[3], nt);
+            atomicAdd(&ctr[4], (unsigned long long)st_iter); atomicAdd(&ctr[5], (unsigned long long)st_act);
+            atomicAdd(&ctr[6], (unsigned long long)st_redo); atomicAdd(&ctr[7], (unsigned long long)st_exch);
+            for (int i = 0; i < 3; ++i) { atomicAdd(&ctr[10 + i], (unsigned long long)st_bat[i]); atomicAdd(&ctr[13 + i], (unsigned long long)st_lan[i]); }
+            for (int i = 0; i < 4; ++i) atomicAdd(&ctr[16 + i], (unsigned long long)ph[i]);
             const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-            atomicAdd(&K.counters[20], t_end - t_start);
-            atomicMax(&K.counters[21], t_end - t_start);             // longest wave
-            if (t_dry) { atomicMax(&K.counters[22], t_end - t_dry); atomicAdd(&K.counters[23], t_end - t_dry); }   // longest / summed drain after the queue ran dry
+            atomicAdd(&ctr[20], t_end - t_start);
+            atomicMax(&ctr[21], t_end - t_start);             // longest wave
         }
     }
 }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 }
                 const uint32_t base = rank < avail ? base_old : base_new - avail;
                 if (need_task) {
-                    task = base + rank;
+                    task = deal_task(base + rank, K.ntasks);      // (spt_device.h: a pixel's blocks go to different waves)
                     task_valid = task < K.ntasks;
                     if (task_valid) {
                         // task = ((pixel * 4 + cell) << nb_log2) | block: one block of a jitter cell's samples (D9)

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
             }
             const uint32_t base = rank < avail ? base_old : base_new - avail;
             if (need_task) {
-                task = base + rank;
+                task = deal_task(base + rank, P.ntasks);             // (spt_device.h: a pixel's blocks go to different waves)
                 task_valid = task < P.ntasks;
                 if (task_valid) {
                     // task = ((pixel * 4 + cell) << nb_log2) | block: one block of a jitter cell's samples (D9)
@@ -266,6 +266,42 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
         // ---- phase D1: closest hit, smallpt.cpp:54-70 over scene.cpp:129-140 (D1, D16).  Branch-free per
         // sphere: det < 0 gives sqrt = NaN and every comparison below is false, like the early return. ----
         bool shade = false;
+        // A wave that has only a few rays left to answer (the end of a launch; one roulette-immune path -- colour (1,1,1) mirror or glass --
+        // bouncing in a closed ball up to the depth cap) answers them ONE BY ONE WITH ALL ITS LANES: lane l tests spheres l, l + 64, ...
+        // in ascending order with strict '<', then the wave takes the lexicographic minimum of (key, index): the key the sequential loop
+        // ends with and the lowest index among the spheres that give it (:61).  n / 64 tests per lane and ray instead of n in one lane.
+        uint32_t coop_key = kInfKey, coop_inst = 0;
+        bool coop = false;
+        if (BIGN) {
+            unsigned long long todo = __ballot(alive && !parked);
+            coop = todo != 0ull && (uint32_t)__popcll(todo) <= 4u && P.n >= 64u;
+            if (coop) {
+                while (todo != 0ull) {
+                    const int rl = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const f3 ro = mk(__shfl(p.o.x, rl), __shfl(p.o.y, rl), __shfl(p.o.z, rl)), rd = mk(__shfl(p.d.x, rl), __shfl(p.d.y, rl), __shfl(p.d.z, rl));
+                    uint32_t wk = kInfKey, wi = 0;
+                    for (uint32_t i = threadIdx.x & 63u; i < P.n; i += 64u) {
+                        const float4 g = s_geom[i];
+                        const f3 op = mk(g.x - ro.x, g.y - ro.y, g.z - ro.z);               // :132
+                        const float b = dot(op, rd);                                         // :133
+                        const float det = b * b - dot(op, op) + g.w;                         // :133
+                        const float sd = GUARD ? sqrt_exact(det) : sqrt_rsq(det);            // :134
+                        const uint32_t key1 = __float_as_uint(b - sd) - kEpsKeyBias;         // :135
+                        const uint32_t key2 = __float_as_uint(b + sd) - kEpsKeyBias;
+                        const uint32_t key = key1 < key2 ? key1 : key2;
+                        if (key < wk) { wk = key; wi = i; }
+                    }
+#pragma unroll 1
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const uint32_t k2 = (uint32_t)__shfl_xor((int)wk, off), i2 = (uint32_t)__shfl_xor((int)wi, off);
+                        const bool better = (k2 < wk) | ((k2 == wk) & (i2 < wi));
+                        wk = better ? k2 : wk; wi = better ? i2 : wi;
+                    }
+                    if ((int)(threadIdx.x & 63u) == rl) { coop_key = wk; coop_inst = wk == kInfKey ? 0u : wi; }
+                }
+            }
+        }
         if (alive && !parked) {
             ++nbounce;
             // Selection on integer keys: for positive floats the bit pattern orders like the value, so with
@@ -287,7 +323,9 @@ __global__ __launch_bounds__(BLOCK) void megakernel(const KParams P)
                 b = dot(op, p.d);                                                      // :133
                 det = b * b - dot(op, op) + g.w;                                       // :133 (g.w = r*r)
             };
-            if (BIGN) {
+            if (coop) {
+                near_key = coop_key; inst = coop_inst;
+            } else if (BIGN) {
                 // Large tables: most spheres are missed by every ray of the wave (det < 0 in all lanes,
                 // scene.cpp:134).  Groups of four spheres share one LDS wait and one wave-uniform test; the
                 // sqrt/selection part runs only for groups in which some lane has det >= 0.  Exact: a skipped

@@ -397,7 +397,8 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
         }
         if (!alive && s_gen == s_end && !queue_empty) {
             if (task_valid) K.cells[task] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-            task = atomicAdd(K.queue, 1u);                    // the triangle loop dwarfs this atomic
+            const uint32_t qpos = atomicAdd(K.queue, 1u);     // the triangle loop dwarfs this atomic
+            task = deal_task(qpos, K.ntasks);                 // (spt_device.h: a pixel's blocks go to different waves)
             task_valid = task < K.ntasks;
             if (task_valid) {
                 const uint32_t cellid = task >> K.nb_log2, blk = task & ((1u << K.nb_log2) - 1u);

@@ -50,13 +50,13 @@ for name, sc, check_rows in scenes:
             it = max(1, d[2])
             out.update({"steps_per_ray": round(d[0] / rays, 2), "tests_per_ray": round(d[1] / rays, 2), "walk_iterations_per_64_rays": round(64 * d[2] / rays, 2),
                         "walking_lanes": round(d[3] / it / 64, 3), "step_lanes": round(d[0] / it / 64, 3), "test_lanes": round(d[1] / it / 64, 3),
-                        "exhaustive_rays": d[4], "exchanges_per_64_rays": round(64 * d[5] / rays, 2), "lanes_per_exchange": round(d[7] / max(1, d[5]), 1),
+                        "exhaustive_rays": d[4], "exchanges_per_64_rays": round(64 * d[5] / rays, 2),
                         "batch_lanes": {k: round(d[11 + i] / max(1, d[8 + i]), 1) for i, k in enumerate(("gen", "hit", "hitr"))},
                         "batches_per_64_rays": {k: round(64 * d[8 + i] / rays, 3) for i, k in enumerate(("gen", "hit", "hitr"))}})
             tot = max(1, d[18])
             out["phase_share"] = {k: round(d[14 + i] / tot, 3) for i, k in enumerate(("walk", "exchange", "gen+begin", "shade+begin"))}
             nw = st["grid_blocks"] * st["block_threads"] // 64
-            out["wave_ms_at_2.4GHz"] = {"mean": round(d[18] / nw / 2.4e6, 2), "longest": round(d[19] / 2.4e6, 2), "drain_mean": round(d[21] / nw / 2.4e6, 2), "drain_longest": round(d[20] / 2.4e6, 2)}
+            out["wave_ms_at_2.4GHz"] = {"mean": round(d[18] / nw / 2.4e6, 2), "longest": round(d[19] / 2.4e6, 2)}
         print(json.dumps(out), flush=True)
         rows.append(out)
 r.set_tuning(0, 0)
