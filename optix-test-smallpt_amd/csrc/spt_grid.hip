@@ -206,13 +206,40 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 asm volatile("" : "+s"(gp));
                 const GridParams& GB = *(const GridParams*)gp;
                 bool ok = false;
+                // A wave with only a few new rays and nobody walking (the end of a launch; a roulette-immune path -- colour (1,1,1) mirror or
+                // glass -- bouncing in a closed ball up to the depth cap) answers each with the exhaustive loop run by ALL its lanes: lane l
+                // tests spheres l, l + 64, ..., then the lexicographic minimum of (key, index) over the wave (below).
+                const unsigned long long mfresh = __ballot(fresh);
+                const bool few = (uint32_t)__popcll(mfresh) <= 4u && __ballot(mode == M_WALK) == 0ull && G.n >= 64u;
                 if (fresh) {
                     if (!redo) ++nbounce;                        // (a ray handed back by its walk was counted when it started)
                     near_key = kGInfKey; near_i = 0u;            // index 0 with the inf key: never replaced by another inf key, never taken for a hit
-                    ok = grid_ray_ok(GB, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, t_ok) && !redo;
+                    ok = grid_ray_ok(GB, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, t_ok) && !redo && !few;
                     if (!ok) t_ok = __builtin_inff();            // the exhaustive loop's answer needs no range
                     redo = false;
                 }
+                if (few) {
+                    unsigned long long todo = mfresh;
+                    if (STATS) n_fallback += (unsigned long long)__popcll(todo);
+                    while (todo != 0ull) {
+                        const int rl = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        const f3 ro = mk(__shfl(p.o.x, rl), __shfl(p.o.y, rl), __shfl(p.o.z, rl)), rd = mk(__shfl(p.d.x, rl), __shfl(p.d.y, rl), __shfl(p.d.z, rl));
+                        uint32_t wk = kGInfKey, wi = 0u;
+                        for (uint32_t i = lane; i < G.n; i += 64u) {
+                            const uint32_t key = sphere_key_g(s_geom[i], ro, rd);
+                            if (key < wk) { wk = key; wi = i; }
+                        }
+#pragma unroll 1
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const uint32_t k2 = (uint32_t)__shfl_xor((int)wk, off), i2 = (uint32_t)__shfl_xor((int)wi, off);
+                            const bool better = (k2 < wk) | ((k2 == wk) & (i2 < wi));
+                            wk = better ? k2 : wk; wi = better ? i2 : wi;
+                        }
+                        if ((int)lane == rl) { near_key = wk; near_i = wk == kGInfKey ? 0u : wi; }
+                    }
+                }
+                if (!few)
                 for (uint32_t k = 0; k < G.nalways; ++k) {       // the walls and the light of a Cornell box: ascending indices, strict '<' (smallpt.cpp:61)
                     const uint32_t i = s_refs[G.nrefs + k];
                     const float4 g = s_geom[i];
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                         if (key < near_key) { near_key = key; near_i = i; }
                     }
                 }
-                const unsigned long long bad = __ballot(fresh && !ok);
+                const unsigned long long bad = few ? 0ull : __ballot(fresh && !ok);
                 if (bad != 0ull) {                               // spt_grid.h (4): the exhaustive loop of smallpt.cpp:54-70
                     if (STATS) n_fallback += (unsigned long long)__popcll(bad);
                     for (uint32_t i = 0; i < G.n; ++i) {

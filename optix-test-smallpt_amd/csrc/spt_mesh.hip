@@ -467,9 +467,39 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
         if (GEOM == 0) { nalive = (uint32_t)__syncthreads_count(alive ? 1 : 0); if (nalive == 0u) break; }
         else if (__ballot(alive) == 0ull) break;
 
-        // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
+        // ---- sphere table, a wave with only a few rays left (the end of a launch; a roulette-immune path -- colour (1,1,1) mirror or glass --
+        // bouncing in a closed ball up to the depth cap): the whole wave answers each ray with the exhaustive loop of smallpt.cpp:54-70
+        // -- lane l tests spheres l, l + 64, ... (coalesced records, ascending, strict '<'), then the lexicographic minimum of
+        // (key, index) over the wave = the loop's key and the lowest index that gives it (:61) -- instead of one lane chasing
+        // dependent node loads through the hierarchy.  Up to 16 384 spheres (256 tests per lane). ----
         float t;
-        const uint32_t tri = GEOM == 2 ? closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
+        uint32_t coop_tri = 0xFFFFFFFFu;
+        bool coop = false;
+        if (GEOM == 2) {
+            unsigned long long todo = __ballot(alive);
+            coop = todo != 0ull && (uint32_t)__popcll(todo) <= 4u && K.n >= 64u && K.n <= 16384u;
+            if (coop) {
+                while (todo != 0ull) {
+                    const int rl = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const f3 ro = mk(__shfl(p.o.x, rl), __shfl(p.o.y, rl), __shfl(p.o.z, rl)), rd = mk(__shfl(p.d.x, rl), __shfl(p.d.y, rl), __shfl(p.d.z, rl));
+                    uint32_t wk = kSphInfKey, wi = 0xFFFFFFFFu;
+                    for (uint32_t i = lane; i < K.n; i += 64u) {
+                        const uint32_t key = sphere_key(K.geom[i], ro, rd);
+                        if (key < wk) { wk = key; wi = i; }
+                    }
+#pragma unroll 1
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const uint32_t k2 = (uint32_t)__shfl_xor((int)wk, off), i2 = (uint32_t)__shfl_xor((int)wi, off);
+                        const bool better = (k2 < wk) | ((k2 == wk) & (i2 < wi));
+                        wk = better ? k2 : wk; wi = better ? i2 : wi;
+                    }
+                    if ((int)lane == rl) { coop_tri = wk < kSphInfKey ? wi : 0xFFFFFFFFu; t = __uint_as_float(wk + kSphEpsBias); }
+                }
+            }
+        }
+        // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
+        const uint32_t tri = GEOM == 2 ? (coop ? coop_tri : closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t))
                            : GEOM == 1 ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
                            : nalive <= (uint32_t)kFewRays ? closest_triangle_few(M.tris, M.ntris, s_tile, nalive, alive, p.o, p.d, t)
                                        : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);

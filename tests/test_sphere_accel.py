@@ -160,6 +160,39 @@ def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle, lane_owned):
 
 
 @pytest.mark.gpu
+def test_deep_paths_in_a_large_table_finish_quickly_in_every_mode(pkg, renderer, oracle):
+    """Case 1369 of the parity fuzzer's default stream at its original size (tests/fuzz_recipe.py: 1500 spheres, 69 of them colour (1,1,1),
+    298 huge; 24 x 12 pixels, 70 samples per jitter cell): 288 paths run to the depth cap of 4096 because some pixels look into closed white
+    mirror / glass balls, where the roulette never kills.  Round 3 needed 2.7 ... 16 s for it -- all sample blocks of such a pixel sat in one
+    wave, which dragged them through its phases long after the others had finished -- and a heavier case of this kind tripped the
+    60-second kernel watchdog.  Since round 4 a pixel's blocks are dealt to different waves (spt_device.h deal_task) and a wave with a few
+    rays left answers them with all its lanes: 0.3 ... 0.6 s in every mode (profiles/r04_fuzz_deep_cases.txt).  Bit-exact image, equal
+    bounce and depth-cap counts, and a time bound a regression of either mechanism would break."""
+    from fuzz_recipe import draw_case
+    rs = np.random.RandomState(1234)
+    for _ in range(1370):
+        case = draw_case(rs, pkg)
+    assert (case["n"], case["w"], case["h"], case["samps"], case["white"]) == (1500, 24, 12, 70, 69)
+    sc = pkg.make_spheres(case["rows"])
+    ref, rst = oracle.render(sc, case["w"], case["h"], case["samps"], seed=case["seed"], normalise=case["norm"])
+    assert rst["max_depth_kills"] == 288
+    try:
+        for mode, accel, lane_owned, kernel in (("path pools", pkg.ACCEL_GRID, False, "gpool"), ("lane-owned", pkg.ACCEL_GRID, True, "grid"),
+                                                ("hierarchy", pkg.ACCEL_BVH, False, "sbvh"), ("exhaustive", pkg.ACCEL_EXHAUSTIVE, False, "mega")):
+            renderer.set_grid_pools(lane_owned=lane_owned)
+            renderer.set_sphere_accel(accel)
+            renderer.set_scene(sc)
+            img, st = renderer.render(case["w"], case["h"], case["samps"], seed=case["seed"], normalise=case["norm"])
+            assert renderer.last_kernel() == kernel, mode
+            assert np.array_equal(img, ref, equal_nan=True), mode
+            assert st["bounces"] == rst["bounces"] and st["max_depth_kills"] == 288, mode
+            assert st["kernel_ms"] < 2000.0, (mode, st["kernel_ms"])
+    finally:
+        renderer.set_grid_pools()
+        renderer.set_sphere_accel(pkg.ACCEL_GRID)
+
+
+@pytest.mark.gpu
 def test_sphere_hierarchy_images_equal_oracle(pkg, renderer, oracle):
     scenes = [("cluster 25", _cluster_scene(pkg, 25, 5)), ("cluster 100", _cluster_scene(pkg, 100, 6)), ("cluster 600", _cluster_scene(pkg, 600, 7)),
               ("open 257", _cluster_scene(pkg, 257, 8, huge=False)), ("config 5", pkg.random_spheres(1024, 1024))]

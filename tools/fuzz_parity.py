@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import optix_test_smallpt_amd as pkg
 import oracle_binding as orc
+from fuzz_recipe import draw_case, camera_of
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 skip = int(os.environ.get("FUZZ_SKIP", "0"))          # replay: draw the first N cases without rendering them (same random sequence)
@@ -16,30 +17,13 @@ r.set_watchdog(wd)
 kernels = {}
 t0 = time.time(); cases = 0; bad = 0; last_note = t0; reordered = 0
 while time.time() - t0 < budget:
-    n = int(rs.choice([1, 2, 3, 5, 9, 17, 24, 25, 40, 100, 257, 600, 1500]))
-    rows = []
-    for i in range(n):
-        kind = rs.rand()
-        rad = float(10 ** rs.uniform(-1, 1.3)) if kind < 0.8 else float(10 ** rs.uniform(2, 5))
-        c = (rs.uniform(-20, 120), rs.uniform(-20, 100), rs.uniform(-50, 250))
-        if kind >= 0.8:   # huge "wall" sphere placed so that the camera is inside or just outside
-            c = tuple(float(v) for v in (np.array([50, 40, 80]) + (rs.randn(3) / np.linalg.norm(rs.randn(3)+1e-9)) * rad * rs.uniform(0.9, 1.1)))
-        e = (0, 0, 0) if rs.rand() < 0.8 else tuple(rs.uniform(0, 5, 3))
-        col = tuple(rs.uniform(0, 1, 3)) if rs.rand() < 0.9 else (0, 0, 0)
-        if rs.rand() < 0.05: col = (1.0, 1.0, 1.0)
-        rows.append((rad, c, e, col, int(rs.choice([0, 0, 0, 1, 2]))))
-    sc = pkg.make_spheres(rows)
-    w, h = int(rs.randint(1, 70)), int(rs.randint(1, 50))
-    samps = int(rs.choice([1, 1, 2, 3, 7, 33, 70, 130]))       # >= 32: several D9 sample blocks per jitter cell
-    if samps > 7:
-        w, h = min(w, 24), min(h, 16)
-    if n > 600:          # a 4096-bounce path (white spheres never die in the roulette) over 1500 spheres costs 0.1-0.3 s on a lone lane, and the oracle as much
-        samps = min(samps, 3)
-        w, h = min(w, 24), min(h, 16)
-    seed = int(rs.randint(0, 2**31)) * int(rs.choice([1, 2**20]))
-    cam = None if rs.rand() < 0.6 else pkg.pinhole_camera(org=(50, 45, 250), vz=(0, 0, -1))
-    norm = bool(rs.rand() < 0.5)
-    accel = [pkg.ACCEL_GRID, pkg.ACCEL_GRID, pkg.ACCEL_BVH, pkg.ACCEL_EXHAUSTIVE][rs.randint(4)]     # tables above 24 spheres: grid (default), hierarchy or megakernel
+    # (round 3 capped tables above 600 spheres at 3 samples per cell here: a pixel that looks into a closed colour-(1,1,1) mirror or glass ball
+    # has every sample run to the depth cap, and one wave dragged all of them.  Since round 4 such a pixel's blocks are dealt to different
+    # waves and a wave with a few rays left answers them with all its lanes (profiles/r04_fuzz_deep_cases.txt): the cap is gone.)
+    case = draw_case(rs, pkg)
+    n, w, h, samps, seed, norm, accel = case["n"], case["w"], case["h"], case["samps"], case["seed"], case["norm"], case["accel"]
+    sc = pkg.make_spheres(case["rows"])
+    cam = camera_of(case, pkg)
     if cases < skip:
         cases += 1
         continue

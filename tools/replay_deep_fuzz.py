@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import optix_test_smallpt_amd as pkg
 import oracle_binding as orc
+from fuzz_recipe import draw_case, camera_of
 
 arg = sys.argv[1] if len(sys.argv) > 1 else "3"
 named = sorted(int(v) for v in arg.split(",")) if "," in arg or int(arg) > 100 else None
@@ -24,26 +25,9 @@ print("| case | spheres (white, huge) | image, samples per cell | mode | kernel 
 print("|---|---|---|---|---|---|---|---|---|---|")
 while found < want:
     case += 1
-    n = int(rs.choice([1, 2, 3, 5, 9, 17, 24, 25, 40, 100, 257, 600, 1500]))
-    rows = []
-    for i in range(n):
-        kind = rs.rand()
-        rad = float(10 ** rs.uniform(-1, 1.3)) if kind < 0.8 else float(10 ** rs.uniform(2, 5))
-        c = (rs.uniform(-20, 120), rs.uniform(-20, 100), rs.uniform(-50, 250))
-        if kind >= 0.8:
-            c = tuple(float(v) for v in (np.array([50, 40, 80]) + (rs.randn(3) / np.linalg.norm(rs.randn(3)+1e-9)) * rad * rs.uniform(0.9, 1.1)))
-        e = (0, 0, 0) if rs.rand() < 0.8 else tuple(rs.uniform(0, 5, 3))
-        col = tuple(rs.uniform(0, 1, 3)) if rs.rand() < 0.9 else (0, 0, 0)
-        if rs.rand() < 0.05: col = (1.0, 1.0, 1.0)
-        rows.append((rad, c, e, col, int(rs.choice([0, 0, 0, 1, 2]))))
-    w, h = int(rs.randint(1, 70)), int(rs.randint(1, 50))
-    samps = int(rs.choice([1, 1, 2, 3, 7, 33, 70, 130]))
-    if samps > 7:
-        w, h = min(w, 24), min(h, 16)
-    seed = int(rs.randint(0, 2**31)) * int(rs.choice([1, 2**20]))
-    cam = None if rs.rand() < 0.6 else pkg.pinhole_camera(org=(50, 45, 250), vz=(0, 0, -1))
-    norm = bool(rs.rand() < 0.5)
-    rs.randint(4)
+    cs = draw_case(rs, pkg)
+    n, w, h, samps, seed, norm, rows = cs["n"], cs["w"], cs["h"], cs["samps"], cs["seed"], cs["norm"], cs["rows"]
+    cam = camera_of(cs, pkg)
     if (named is not None and case not in named) or (named is None and (n != 1500 or samps < 33)):
         continue
     found += 1
