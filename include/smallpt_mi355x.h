@@ -91,6 +91,8 @@ typedef struct spt_stats {
 } spt_stats;
 
 #define SPT_FLAG_NORMALISE 1u  /* divide by spp (cpuRender); otherwise return the raw sum (render()) */
+#define SPT_FLAG_ONE_SHOT  2u  /* scheduling only: this launch neither uses nor records a dispatch order (see spt_render_rows_device): a caller
+                                * that will not render the view again saves the clock stores, three small kernels and the order tables */
 #define SPT_MAX_DEPTH      4096u
 #define SPT_MAX_SPHERES    4096u  /* the exhaustive kernels stage the table in LDS: 16 B geometry per sphere */
 #define SPT_MAX_SPHERES_ACCEL 1048576u  /* through a structure (spt_set_sphere_accel: the grid up to about 9 000 spheres, the hierarchy beyond) */
@@ -196,8 +198,10 @@ int  spt_render(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
  * Pixel/sample RNG keys use the GLOBAL pixel index, so any row partition over any number of GPUs
  * yields the same image.  Call spt_sync() before reading stats.
  * Scheduling only (never the result): for tables of <= 24 spheres and >= 16 samples per cell a context remembers how long each group
- * of sample blocks took in its last launch, and a launch of the same scene, camera, image, band and sample count (any seed) starts the
- * expensive ones first -- a view's second and later launches are ~5 % shorter at 1024 spp than its first. */
+ * of sample blocks took in its last launch, and a launch of the same scene, camera, image, band, sample count AND SEED starts the
+ * expensive ones first: re-rendering a view is ~4 % shorter at 1024 spp than rendering it the first time (79.4 -> 76.3 ms on config 2).
+ * Another seed of the view runs in the static order like a first launch -- measured, the previous seed's order makes it 1 % SLOWER
+ * (profiles/r04_cost_order_seeds.txt; round 3 claimed the gain for any seed without having stepped it).  SPT_FLAG_ONE_SHOT opts a launch out. */
 int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
                             uint32_t row_begin, uint32_t row_count,
                             uint32_t samps_per_cell, uint64_t seed, uint32_t flags,

@@ -1005,23 +1005,30 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         P.stack = c->d_stack;
         P.slot_state = reinterpret_cast<uint2*>(c->d_stack + stack_floats);
         P.watchdog_ticks = c->watchdog_ticks;
-        // Cost-ordered dispatch: the queue hands out chunks of 64 tasks; every launch records how long each chunk kept its wave
-        // busy, and a launch of the SAME view (scene, camera, image, band, samples -- a repeated render, a progressive loop's next frame; the seed
-        // may differ, a pixel's cost is a property of what it looks at) starts the expensive chunks first.  Results do not depend on
-        // the dispatch order.  Tuning bit 13 switches it off for this kernel (A/B).
+        // Cost-ordered dispatch: the queue hands out chunks of 64 tasks; every launch records how long each chunk kept its wave busy, and a
+        // launch of the SAME view with the SAME seed (a repeated render) starts the expensive chunks first.  Round 3 applied the order to
+        // any seed of the view ("a pixel's cost is a property of what it looks at"); measured with the seed stepped every launch that is
+        // wrong at the granularity of a chunk -- 80.4-80.7 ms against 79.3-79.7 in the static order, also when only the most expensive
+        // 1/64 of the chunks is moved to the front (profiles/r04_cost_order_seeds.txt): a chunk's time is mostly the luck of its 2048
+        // samples and of when its wave ran it -- so the seed is part of the key now, and a new seed runs in the static order like a first
+        // launch.  Results do not depend on the dispatch order.  Tuning bit 13 switches it off for this kernel (A/B), SPT_FLAG_ONE_SHOT
+        // for one launch (nothing is recorded either: no clock stores, no ordering kernels, no tables).
         const uint32_t nchunks = (uint32_t)((ntasks + 63) / 64);
-        std::vector<unsigned char> key(sizeof(spt_camera) + 10 * sizeof(uint32_t) + sizeof(uint64_t));
+        std::vector<unsigned char> key(sizeof(spt_camera) + 10 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
         {
             unsigned char* k = key.data();
             std::memcpy(k, cam, sizeof(spt_camera)); k += sizeof(spt_camera);
             const uint32_t words[10] = {w, h, row_begin, row_count, rb_log2, rb_stride, rb_mask, samps, c->variant, (uint32_t)blocks};
             std::memcpy(k, words, sizeof words); k += sizeof words;
-            std::memcpy(k, &c->scene_gen, sizeof(uint64_t));
+            std::memcpy(k, &c->scene_gen, sizeof(uint64_t)); k += sizeof(uint64_t);
+            std::memcpy(k, &seed, sizeof(uint64_t));
         }
         if (c->order_pending) { SPT_HIP(c, hipStreamWaitEvent(st, c->ev_order, 0)); c->order_pending = false; }
         // (not for the viewer's frames of a few samples per cell: a chunk's time is then the luck of 64 single paths, and the order kernel
         // between two frames costs the frames in flight more than it gains; bit 13 means something else to the grid kernel only)
-        if (!(c->variant & 0x2000u) && samps >= 16u) {
+        // (... and not beyond 4 Mi chunks -- 48 MB of tables; a single band of config 4's size is 1 Mi --: the tail the order removes is a
+        // fixed few milliseconds, nothing of a launch that long)
+        if (!(c->variant & 0x2000u) && !(flags & SPT_FLAG_ONE_SHOT) && samps >= 16u && nchunks <= (4u << 20)) {
             if (nchunks > c->chunk_cap) {
                 if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
                 c->d_chunk_tables = nullptr; c->chunk_cap = 0; c->order_valid = false;

@@ -13,6 +13,7 @@ from ._lib import SptCamera, SptMaterial, SptMesh, SptMultiStats, SptStats, load
 from .scene import HIT_DTYPE, RAY_DTYPE, SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
+FLAG_ONE_SHOT = 2          # scheduling only: no dispatch order used or recorded for this launch (include/smallpt_mi355x.h)
 ACCEL_EXHAUSTIVE, ACCEL_BVH, ACCEL_GRID = 0, 1, 2
 
 

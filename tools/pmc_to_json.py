@@ -1,6 +1,7 @@
 """Turns a tools/prof_pmc.sh summary (gpurun_out/<tag>_summary.txt) into profiles/pmc_latest.json, the PMC-derived
 constants bench.py prints beside its live timing (roofline.traffic and roofline.decomposition).
-usage: python tools/pmc_to_json.py gpurun_out/r02_pmc_summary.txt [kernel-substring]"""
+usage: python tools/pmc_to_json.py gpurun_out/r02_pmc_summary.txt [kernel-substring] [kernel_ms of the profiled launches]"""
+import subprocess
 import json
 import os
 import re
@@ -34,6 +35,9 @@ out = {
     "FETCH_SIZE_KiB": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB": c.get("WRITE_SIZE"),
     "hbm_bytes_per_launch": int(c["WRITE_SIZE"] * 1024 + 2 * c["FETCH_SIZE"] * 1024) if "WRITE_SIZE" in c and "FETCH_SIZE" in c else None,
     "algorithmic_bytes_per_launch": 1024 * 768 * 12,
+    # provenance for bench.py's roofline.from_committed_profile: the kernel time the counters were collected at and the source they belong to
+    "kernel_ms": float(sys.argv[3]) if len(sys.argv) > 3 else (c["GRBM_GUI_ACTIVE"] / (8 * 2.4e6) if "GRBM_GUI_ACTIVE" in c else None),
+    "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None,
 }
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
