@@ -115,7 +115,8 @@ MULTI_SYMBOLS = {
     "spt_multi_progressive_end": (C.c_int, [_P]),
 }
 
-MULTI_INTERNAL_SYMBOLS = {"spt_multi_set_rank_watchdog": (C.c_int, [_P, C.c_uint32, C.c_double])}   # csrc/spt_internal.h
+MULTI_INTERNAL_SYMBOLS = {"spt_multi_set_rank_watchdog": (C.c_int, [_P, C.c_uint32, C.c_double]),   # csrc/spt_internal.h
+                          "spt_multi_inject_exchange_failure": (C.c_int, [_P, C.c_uint32])}
 
 _lib = None
 _multi_lib = None

@@ -80,6 +80,10 @@ int  spt_selftest_sphere_grid(const spt_sphere* spheres, uint32_t n, uint32_t ce
  * device's render fail and check that spt_multi_render returns its error instead of hanging in the exchange. */
 struct spt_multi;
 int  spt_multi_set_rank_watchdog(struct spt_multi* m, uint32_t rank, double seconds);
+/* ... and a failure INSIDE the exchange: `rank` fails its part of the next RCCL exchange after every rank's rows are complete.  The failing
+ * rank aborts every communicator (ncclCommAbort) so that no peer stays blocked in a send / receive; spt_multi_render returns its error and
+ * the next call builds new communicators. */
+int  spt_multi_inject_exchange_failure(struct spt_multi* m, uint32_t rank);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,32 @@ struct spt_multi {
     float* d_accum = nullptr;      // root device: accumBuffer of the progressive loop (spt_multi_progressive_*), w*h*3 floats
     uint32_t prog_w = 0, prog_h = 0;
     std::string error;
+    // failure inside the exchange (phase 2 of spt_multi_render): the first rank that sees an error aborts EVERY communicator so that
+    // no peer stays blocked in a send / receive whose partner will never come; the next render builds new communicators
+    std::vector<int> device_ids;
+    std::mutex comm_mutex;
+    bool comms_alive = false;
+    int fail_exchange_rank = -1;   // test hook (spt_internal.h spt_multi_inject_exchange_failure): this rank fails inside its next exchange
+
+    void abort_comms()
+    {
+        std::lock_guard<std::mutex> l(comm_mutex);
+        if (!comms_alive) return;
+        comms_alive = false;
+        for (auto& r : ranks)
+            if (r.comm) { (void)ncclCommAbort(r.comm); r.comm = nullptr; }      // frees the communicator; in-flight operations end with an error
+    }
+    int init_comms()
+    {
+        std::lock_guard<std::mutex> l(comm_mutex);
+        if (comms_alive) return 0;
+        std::vector<ncclComm_t> comms(ranks.size());
+        const ncclResult_t e = ncclCommInitAll(comms.data(), (int)ranks.size(), device_ids.data());
+        if (e != ncclSuccess) return fail("ncclCommInitAll over %d device(s): %s", (int)ranks.size(), ncclGetErrorString(e));
+        for (size_t i = 0; i < ranks.size(); ++i) ranks[i].comm = comms[i];
+        comms_alive = true;
+        return 0;
+    }
 
     int fail(const char* fmt, ...)
     {
@@ -139,6 +165,17 @@ struct spt_multi {
         ncclResult_t e__ = (call);                                                             \
         if (e__ != ncclSuccess) { (r).error = std::string(#call) + ": " + ncclGetErrorString(e__); return; } \
     } while (0)
+// inside the exchange: a failing rank takes every communicator down before it returns (spt_multi::abort_comms)
+#define XK_HIP(m, r, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) { (r).error = std::string(#call) + ": " + hipGetErrorString(e__); (m)->abort_comms(); return; } \
+    } while (0)
+#define XK_NCCL(m, r, call)                                                                    \
+    do {                                                                                       \
+        ncclResult_t e__ = (call);                                                             \
+        if (e__ != ncclSuccess) { (r).error = std::string(#call) + ": " + ncclGetErrorString(e__); (m)->abort_comms(); return; } \
+    } while (0)
 
 extern "C" {
 
@@ -160,7 +197,7 @@ void spt_multi_destroy(spt_multi* m)
             Rank& r = m->ranks[(size_t)i];
             (void)hipSetDevice(r.device);
             if (r.stream) (void)hipStreamSynchronize(r.stream);
-            if (r.comm) (void)ncclCommDestroy(r.comm);
+            if (r.comm) (void)ncclCommDestroy(r.comm);             // (null after an aborted exchange)
             if (r.d_band) (void)hipFree(r.d_band);
             if (i == 0 && m->d_frame) (void)hipFree(m->d_frame);
             if (i == 0 && m->d_staging) (void)hipFree(m->d_staging);
@@ -203,14 +240,8 @@ int spt_multi_create(const int* device_ids, int ndev, uint32_t flags, spt_multi*
         RK_HIP(r, hipEventCreate(&r.ev_a));
         RK_HIP(r, hipEventCreate(&r.ev_b));
     });
-    if (rc == 0 && m->use_rccl) {
-        // single-process communicator over all devices (rank i = device_ids[i]); ncclCommInitAll handles the grouping
-        std::vector<ncclComm_t> comms((size_t)ndev);
-        const ncclResult_t e = ncclCommInitAll(comms.data(), ndev, device_ids);
-        if (e != ncclSuccess) rc = m->fail("ncclCommInitAll over %d device(s): %s", ndev, ncclGetErrorString(e));
-        else
-            for (int i = 0; i < ndev; ++i) m->ranks[(size_t)i].comm = comms[(size_t)i];
-    }
+    m->device_ids.assign(device_ids, device_ids + ndev);
+    if (rc == 0 && m->use_rccl) rc = m->init_comms();       // single-process communicators over all devices (rank i = device_ids[i]); ncclCommInitAll handles the grouping
     if (rc) {
         g_multi_create_error = "spt_multi_create: " + m->error;
         spt_multi_destroy(m);
@@ -283,6 +314,14 @@ int spt_multi_set_rank_watchdog(spt_multi* m, uint32_t rank, double seconds)
 {
     if (!m || rank >= m->ranks.size()) return 1;
     return spt_set_watchdog(m->ranks[rank].ctx, seconds);
+}
+
+// Test hook (csrc/spt_internal.h): `rank` fails inside its part of the next RCCL exchange, after every rank's rows are complete
+int spt_multi_inject_exchange_failure(spt_multi* m, uint32_t rank)
+{
+    if (!m || rank >= m->ranks.size()) return 1;
+    m->fail_exchange_rank = (int)rank;
+    return 0;
 }
 
 void* spt_multi_framebuffer(spt_multi* m) { return m ? m->d_frame : nullptr; }
@@ -362,22 +401,24 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
 
     // 2. the exchange step (RCCL): every rank's rows are complete
     if (m->use_rccl) {
+        if (m->init_comms()) return 1;                        // (new communicators after an exchange that was aborted)
         rc = m->on_all([=, &stage_off](int i) {
             Rank& r = m->ranks[(size_t)i];
             const uint32_t count = rows_of((uint32_t)i, nullptr);
             const size_t band_fl = (size_t)count * w * 3;
-            RK_HIP(r, hipSetDevice(r.device));
-            RK_HIP(r, hipEventRecord(r.ev_a, r.stream));
+            XK_HIP(m, r, hipSetDevice(r.device));
+            if (m->fail_exchange_rank == i) { m->fail_exchange_rank = -1; r.error = "injected exchange failure (test hook)"; m->abort_comms(); return; }
+            XK_HIP(m, r, hipEventRecord(r.ev_a, r.stream));
             if (i == 0) {
-                RK_NCCL(r, ncclGroupStart());
+                XK_NCCL(m, r, ncclGroupStart());
                 for (uint32_t p = self_exchange ? 0u : 1u; p < world; ++p) {
                     uint32_t pb = 0;
                     const uint32_t pc = rows_of(p, &pb);
                     float* to = interleaved ? m->d_staging + stage_off[p] : m->d_frame + (size_t)pb * w * 3;
-                    if (pc) RK_NCCL(r, ncclRecv(to, (size_t)pc * w * 3, ncclFloat, (int)p, r.comm, r.stream));
+                    if (pc) XK_NCCL(m, r, ncclRecv(to, (size_t)pc * w * 3, ncclFloat, (int)p, r.comm, r.stream));
                 }
-                if (self_exchange && count) RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
-                RK_NCCL(r, ncclGroupEnd());
+                if (self_exchange && count) XK_NCCL(m, r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
+                XK_NCCL(m, r, ncclGroupEnd());
                 if (interleaved) {
                     // scatter every rank's packed row blocks to their rows: block k of rank p starts at row (k * world + p) * B
                     for (uint32_t p = 0; p < world; ++p) {
@@ -387,21 +428,21 @@ int spt_multi_render(spt_multi* m, const spt_camera* cam, uint32_t w, uint32_t h
                         const size_t block_bytes = (size_t)kBlockRows * w * 3 * sizeof(float);
                         const uint32_t full = pc / kBlockRows, rest = pc % kBlockRows;
                         if (full)
-                            RK_HIP(r, hipMemcpy2DAsync(m->d_frame + (size_t)p * kBlockRows * w * 3, block_bytes * world, from, block_bytes,
+                            XK_HIP(m, r, hipMemcpy2DAsync(m->d_frame + (size_t)p * kBlockRows * w * 3, block_bytes * world, from, block_bytes,
                                                        block_bytes, full, hipMemcpyDeviceToDevice, r.stream));
                         if (rest)
-                            RK_HIP(r, hipMemcpyAsync(m->d_frame + ((size_t)full * world + p) * kBlockRows * w * 3, from + (size_t)full * kBlockRows * w * 3,
+                            XK_HIP(m, r, hipMemcpyAsync(m->d_frame + ((size_t)full * world + p) * kBlockRows * w * 3, from + (size_t)full * kBlockRows * w * 3,
                                                      (size_t)rest * w * 3 * sizeof(float), hipMemcpyDeviceToDevice, r.stream));
                     }
                 }
             } else if (count) {
-                RK_NCCL(r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
+                XK_NCCL(m, r, ncclSend(r.d_band, band_fl, ncclFloat, 0, r.comm, r.stream));
             }
-            RK_HIP(r, hipEventRecord(r.ev_b, r.stream));
-            RK_HIP(r, hipStreamSynchronize(r.stream));
-            RK_HIP(r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
+            XK_HIP(m, r, hipEventRecord(r.ev_b, r.stream));
+            XK_HIP(m, r, hipStreamSynchronize(r.stream));
+            XK_HIP(m, r, hipEventElapsedTime(&r.gather_ms, r.ev_a, r.ev_b));
         });
-        if (rc) return rc;
+        if (rc) { m->abort_comms(); return rc; }              // (a rank that failed has aborted them already; idempotent)
     }
 
     // 2'. copy transport (SPT_MULTI_COPY_EXCHANGE): every rank has finished its rows (stream synchronised above); the root

@@ -332,6 +332,10 @@ class MultiRenderer:
         """Test hook (csrc/spt_internal.h): kernel watchdog of one rank's context."""
         self._check(self._lib.spt_multi_set_rank_watchdog(self._h, int(rank), float(seconds)))
 
+    def inject_exchange_failure(self, rank):
+        """Test hook (csrc/spt_internal.h): `rank` fails inside its part of the next RCCL exchange."""
+        self._check(self._lib.spt_multi_inject_exchange_failure(self._h, int(rank)))
+
     def render(self, w, h, samps_per_cell, seed=0, normalise=False, camera=None, to_host=True):
         """Returns ((h, w, 3) float32 image or None, stats dict); with to_host=False the framebuffer stays on the root
         device (``framebuffer_ptr()``)."""

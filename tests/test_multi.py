@@ -145,6 +145,29 @@ def test_failed_rank_returns_its_error_and_the_object_stays_usable(pkg, renderer
 
 
 @pytest.mark.gpu
+def test_failure_inside_the_exchange_aborts_the_communicators_and_the_next_render_rebuilds_them(pkg, renderer):
+    """A failure INSIDE phase 2 (every rank's rows are complete, the send / receives are being enqueued): the failing rank must take every
+    communicator down (ncclCommAbort) before it returns, so that no peer stays blocked in a send / receive whose partner never comes;
+    spt_multi_render returns that rank's error, and the next call builds new communicators (ncclCommInitAll) and renders the correct
+    image.  One rank whose band goes through RCCL (grouped self send / receive) -- the only RCCL exchange a one-GPU box can run --, the
+    failure injected by the hook of csrc/spt_internal.h; twice in a row, so that an abort after a rebuild is covered too."""
+    w, h, samps, seed = 48, 40, 2, 9
+    sc = pkg.cornell9()
+    renderer.set_scene(sc)
+    ref, rst = renderer.render(w, h, samps, seed=seed, normalise=True)
+    with pkg.MultiRenderer((0,), self_exchange=True) as m:
+        m.set_scene(sc)
+        img, st = m.render(w, h, samps, seed=seed, normalise=True)
+        assert np.array_equal(img, ref)
+        for _ in range(2):
+            m.inject_exchange_failure(0)
+            with pytest.raises(pkg.SptError, match="injected exchange failure"):
+                m.render(w, h, samps, seed=seed, normalise=True)
+            img, st = m.render(w, h, samps, seed=seed, normalise=True)
+            assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+
+
+@pytest.mark.gpu
 def test_multi_mesh_scene_and_accel_pass_throughs(pkg, renderer):
     """spt_multi_set_meshes / set_mesh_accel / set_sphere_accel: the triangle scene the reference ships and a large sphere table
     over three ranks sharing the device -- the same images as the single-context renderer."""
