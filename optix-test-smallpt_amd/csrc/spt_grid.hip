@@ -48,17 +48,27 @@ __device__ __forceinline__ uint32_t sphere_key_g(const float4 g, f3 o, f3 d)
 struct GPath { f3 o, d, w; uint32_t depth, branch, rbase; };
 
 // STATS: walk statistics and per-phase wave time (s_memtime) for tools/bench_grid.py; the product build carries none of it
-template <bool STATS>
+// GLOBAL_TABLES (round 4): sphere records, cell headers and references are read where they lie in global memory (L2 / Infinity-Cache
+// resident: 16 384 spheres are 0.26 MB of records + 0.5 MB of grid) instead of one CU's LDS -- tables beyond the LDS keep the grid (the same
+// walk, the same proof, spt_grid.h) instead of falling to the one-lane-per-path hierarchy.  The always-tested list is read from its own array.
+template <bool STATS, bool GLOBAL_TABLES>
 __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
                                                          const uint16_t* __restrict__ g_refs, const uint32_t* __restrict__ g_always, uint32_t leave_q)
 {
-    extern __shared__ float4 s_geom[];                           // n sphere records, then the grid tables
-    uint32_t* const s_cells = reinterpret_cast<uint32_t*>(s_geom + (G.n ? G.n : 1u));
-    uint16_t* const s_refs = reinterpret_cast<uint16_t*>(s_cells + G.ncells);   // nrefs cell references, then the always-tested list, one spare
-    for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) s_geom[i] = K.geom[i];
-    for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) s_cells[i] = g_cells[i];
-    for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_refs[i] = g_refs[i];
-    for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
+    extern __shared__ float4 s_lds_geom[];                       // n sphere records, then the grid tables (not GLOBAL_TABLES)
+    uint32_t* const s_lds_cells = reinterpret_cast<uint32_t*>(s_lds_geom + (G.n ? G.n : 1u));
+    uint16_t* const s_lds_refs = reinterpret_cast<uint16_t*>(s_lds_cells + G.ncells);   // nrefs cell references, then the always-tested list, one spare
+    if (!GLOBAL_TABLES) {
+        for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) s_lds_geom[i] = K.geom[i];
+        for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) s_lds_cells[i] = g_cells[i];
+        for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_lds_refs[i] = g_refs[i];
+        for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_lds_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
+    }
+    // (the template argument decides the address space at compile time: LDS reads or global loads, never generic ones)
+    auto geom_at = [&](uint32_t i) -> float4 { return GLOBAL_TABLES ? K.geom[i] : s_lds_geom[i]; };
+    auto cell_at = [&](uint32_t ci) -> uint32_t { return GLOBAL_TABLES ? g_cells[ci] : s_lds_cells[ci]; };
+    auto ref_at = [&](uint32_t k) -> uint32_t { return GLOBAL_TABLES ? (uint32_t)g_refs[k] : (uint32_t)s_lds_refs[k]; };
+    auto always_at = [&](uint32_t k) -> uint32_t { return GLOBAL_TABLES ? g_always[k] : (uint32_t)s_lds_refs[G.nrefs + k]; };
     __syncthreads();
 
     const uint32_t lane = lane_id_g();
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                         const f3 ro = mk(__shfl(p.o.x, rl), __shfl(p.o.y, rl), __shfl(p.o.z, rl)), rd = mk(__shfl(p.d.x, rl), __shfl(p.d.y, rl), __shfl(p.d.z, rl));
                         uint32_t wk = kGInfKey, wi = 0u;
                         for (uint32_t i = lane; i < G.n; i += 64u) {
-                            const uint32_t key = sphere_key_g(s_geom[i], ro, rd);
+                            const uint32_t key = sphere_key_g(geom_at(i), ro, rd);
                             if (key < wk) { wk = key; wi = i; }
                         }
 #pragma unroll 1
@@ -241,8 +251,8 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 }
                 if (!few)
                 for (uint32_t k = 0; k < G.nalways; ++k) {       // the walls and the light of a Cornell box: ascending indices, strict '<' (smallpt.cpp:61)
-                    const uint32_t i = s_refs[G.nrefs + k];
-                    const float4 g = s_geom[i];
+                    const uint32_t i = always_at(k);
+                    const float4 g = geom_at(i);
                     if (fresh && ok) {
                         const uint32_t key = sphere_key_g(g, p.o, p.d);
                         if (key < near_key) { near_key = key; near_i = i; }
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                 if (bad != 0ull) {                               // spt_grid.h (4): the exhaustive loop of smallpt.cpp:54-70
                     if (STATS) n_fallback += (unsigned long long)__popcll(bad);
                     for (uint32_t i = 0; i < G.n; ++i) {
-                        const float4 g = s_geom[i];
+                        const float4 g = geom_at(i);
                         if (fresh && !ok) {
                             const uint32_t key = sphere_key_g(g, p.o, p.d);
                             if (key < near_key) { near_key = key; near_i = i; }
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                         GridWalk w;
                         grid_walk_begin(GB, p.o.x, p.o.y, p.o.z, p.d.x, p.d.y, p.d.z, w);
                         wtx = w.tx; wty = w.ty; wtz = w.tz; wdx = w.dtx; wdy = w.dty; wdz = w.dtz; wsx = w.sx; wsy = w.sy; wsz = w.sz; wci = w.ci;
-                        const uint32_t h = s_cells[wci];         // the start cell is clamped into the table: never a border cell
+                        const uint32_t h = cell_at(wci);          // the start cell is clamped into the table: never a border cell
                         cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
                         mode = M_WALK;
                     } else {
@@ -286,9 +296,9 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                     // ---- TEST: the next sphere of the lane's cell ----
                     if (STATS) { ++n_test_iters; n_tests += nt; }
                     if (wt) {
-                        const uint32_t i = s_refs[cur];
+                        const uint32_t i = ref_at(cur);
                         ++cur;
-                        const uint32_t key = sphere_key_g(s_geom[i], p.o, p.d);
+                        const uint32_t key = sphere_key_g(geom_at(i), p.o, p.d);
                         // a sphere may be listed in several cells and cells are not visited in index order: lowest index among equal keys
                         const bool better = (key < near_key) | ((key == near_key) & (i < near_i));
                         near_key = better ? key : near_key;
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
                         bool stop = !(m < near_t);               // spt_grid.h (3): every cell up to the hit has been visited
                         if (!stop) {
                             grid_walk_step(wtx, wty, wtz, wdx, wdy, wdz, wsx, wsy, wsz, wci, m);
-                            const uint32_t h = s_cells[wci];
+                            const uint32_t h = cell_at(wci);
                             stop = h == kGridBorder;             // left the table
                             cur = h >> kGridCountBits; end = cur + (h & ((1u << kGridCountBits) - 1u));
                         }
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const 
             if (near_key != kGInfKey) {                                                // else :168 miss (D13)
                 const uint32_t inst = near_i;
                 const float t = __uint_as_float(near_key + kGEpsBias);
-                const float4 gh = s_geom[inst];
+                const float4 gh = geom_at(inst);
                 const float4 me = K.mat[3 * inst + 0], mc = K.mat[3 * inst + 1];
                 const int refl = __float_as_int(me.w) & 3;
                 const f3 hx = p.o + p.d * t;                                           // scene.cpp:137
@@ -435,14 +445,20 @@ extern "C" int spt_grid_block_threads(void) { return spt::kGridBlock; }
 extern "C" size_t spt_grid_stack_floats(uint32_t blocks, uint32_t threads) { return (size_t)blocks * threads * 36u; }
 
 extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
-                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, hipStream_t stream)
+                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, int global_tables, hipStream_t stream)
 {
     if (threads == 0 || threads > (uint32_t)spt::kGridBlock || (threads & 63u)) return hipErrorInvalidValue;
-    const size_t lds = spt_grid_lds_bytes(G);
-    const void* fn = stats ? reinterpret_cast<const void*>(&spt::gridkernel<true>) : reinterpret_cast<const void*>(&spt::gridkernel<false>);
+    const size_t lds = global_tables ? 0 : spt_grid_lds_bytes(G);
+    const void* fn = global_tables ? (stats ? reinterpret_cast<const void*>(&spt::gridkernel<true, true>) : reinterpret_cast<const void*>(&spt::gridkernel<false, true>))
+                                   : (stats ? reinterpret_cast<const void*>(&spt::gridkernel<true, false>) : reinterpret_cast<const void*>(&spt::gridkernel<false, false>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (stats) hipLaunchKernelGGL(spt::gridkernel<true>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
-    else hipLaunchKernelGGL(spt::gridkernel<false>, dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+    if (global_tables) {
+        if (stats) hipLaunchKernelGGL((spt::gridkernel<true, true>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+        else hipLaunchKernelGGL((spt::gridkernel<false, true>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+    } else {
+        if (stats) hipLaunchKernelGGL((spt::gridkernel<true, false>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+        else hipLaunchKernelGGL((spt::gridkernel<false, false>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
+    }
     return hipGetLastError();
 }

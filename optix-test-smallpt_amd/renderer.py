@@ -178,7 +178,7 @@ class Renderer:
     def set_grid_pools(self, lane_owned=False, slots=0, ready=0, drain=0, min_batch=0, walk_iters=0):
         """Large sphere tables (csrc/spt_internal.h spt_set_grid_pools): keep the lane-owned grid kernel, or set the pool geometry of the
         default one (0 = default).  Results never depend on it."""
-        self._check(self._lib.spt_set_grid_pools(self._h, int(bool(lane_owned)), slots, ready, drain, min_batch, walk_iters))
+        self._check(self._lib.spt_set_grid_pools(self._h, int(lane_owned), slots, ready, drain, min_batch, walk_iters))   # (2: lane-owned with the tables in global memory, A/B)
         self._state["grid_pools"] = (bool(lane_owned), slots, ready, drain, min_batch, walk_iters)
         self._state_version += 1
 

@@ -106,11 +106,12 @@ def test_sphere_grid_images_equal_oracle(pkg, renderer, oracle, lane_owned):
               # some of these 4096 are concentric with the wall spheres (centres 1e5 away): the extent is 1e5 long, nearly everything
               # shares a cell, the grid declines (spt_api.cpp build_sphere_grid_tables) and from 1024 spheres on the hierarchy takes over
               ("cluster 4096", _cluster_scene(pkg, 4096, 9)),
-              # sphere records beyond one CU's LDS: the hierarchy by default
-              ("random 12000", pkg.random_spheres(12000, 11))]
+              # sphere records beyond one CU's LDS: the grid with its tables in global memory (spt_grid.hip GLOBAL_TABLES) up to 24 576 spheres,
+              # the hierarchy beyond
+              ("random 12000", pkg.random_spheres(12000, 11)), ("random 30000", pkg.random_spheres(30000, 12))]
     name_of = "grid" if lane_owned else "gpool"
     # 4096 sphere records + their grid leave no room for the pools' begun walks: the lane-owned kernel keeps such tables
-    expect = {"cluster 4096": "sbvh", "random 12000": "sbvh", "random 4096": "grid"}
+    expect = {"cluster 4096": "sbvh", "random 12000": "grid", "random 30000": "sbvh", "random 4096": "grid"}
     try:
         renderer.set_grid_pools(lane_owned=lane_owned)
         for name, sc in scenes:
