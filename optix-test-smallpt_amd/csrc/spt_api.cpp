@@ -83,7 +83,8 @@ struct spt_ctx {
     hipEvent_t ev_acc = nullptr;   // owner of an accumBuffer: completion of the most recent accumulation (any lane's stream)
     bool acc_recorded = false;
     bool frame_in_flight = false;  // a spt_progressive_frame_async of this lane has not been waited for
-    uint32_t lanes_attached = 0;   // owner: lanes attached so far (spreads them over the stream priorities)
+    uint32_t lanes_attached = 0;   // owner: lanes attached right now (spreads them over the stream priorities, sizes short launches)
+    spt_ctx* attached_to = nullptr; // lane: the owner it is attached to (its count is given back when the lane ends or re-attaches)
     uint32_t frames_in_flight_hint = 1;   // set by spt_progressive_frame_async for its launch: lanes of the loop (sizes a short launch's grid)
     unsigned long long pool_stats[24] = {};  // batches per class [3], lanes per class [3], watchdog hits, tail batches, tail lanes, full batches
     // scratch
@@ -247,6 +248,9 @@ int spt_set_grid_pools(spt_ctx* c, int lane_owned, uint32_t slots, uint32_t read
 int spt_set_tuning(spt_ctx* c, uint32_t blocks_per_cu, uint32_t variant)
 {
     if (!c) return 1;
+    const uint32_t psel = (variant >> 11) & 3u;                   // pool slots per wave: 1 -> 96 and 2 -> 192 exist in -DSPT_POOL_SIZES builds only
+    const int pool = psel == 1 ? 96 : (psel == 2 ? 192 : (psel == 3 ? 128 : spt_pool_default_slots()));
+    if (!spt_pool_has_size(pool)) return c->fail("spt_set_tuning: this build carries no pool kernel with %d slots per wave (bits 12:11 = %u)", pool, psel);
     c->blocks_per_cu = blocks_per_cu;
     c->variant = variant;
     return 0;
@@ -1214,6 +1218,10 @@ int spt_progressive_end(spt_ctx* c)
     c->acc_recorded = false;
     c->frame_in_flight = false;
     c->lanes_attached = 0;
+    if (c->attached_to) {                                           // a lane: its owner's live count (lanes end before their owner does)
+        if (c->attached_to->lanes_attached) --c->attached_to->lanes_attached;
+        c->attached_to = nullptr;
+    }
     return 0;
 }
 
@@ -1254,6 +1262,7 @@ int spt_progressive_attach(spt_ctx* lane, spt_ctx* owner)
     SPT_HIP(lane, hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio));
     SPT_HIP(lane, hipMalloc(reinterpret_cast<void**>(&lane->d_frame), (size_t)owner->prog_w * owner->prog_h * 3 * sizeof(float)));
     lane->prog_w = owner->prog_w; lane->prog_h = owner->prog_h;
+    lane->attached_to = owner;
     return 0;
 }
 
@@ -1264,6 +1273,9 @@ int spt_progressive_frame_async(spt_ctx* c, spt_ctx* owner, const spt_camera* ca
     if (!c->d_frame || c->prog_w != owner->prog_w || c->prog_h != owner->prog_h)
         return c->fail("spt_progressive_frame_async: call spt_progressive_attach(lane, owner) first");
     if (c->frame_in_flight) return c->fail("spt_progressive_frame_async: the lane's previous frame has not been waited for");
+    // a lane renders ITS context's scene into the owner's accumBuffer: the caller keeps the scenes equal; what can be told apart cheaply is
+    if (c != owner && (c->mesh_scene != owner->mesh_scene || (!c->mesh_scene && c->n != owner->n) || (c->mesh_scene && (c->ntris != owner->ntris || c->ninst != owner->ninst))))
+        return c->fail("spt_progressive_frame_async: the lane's scene differs from the owner's (kind or size); set the owner's scene on every lane");
     // :922 the frame is the UN-NORMALISED sum of Renderer::render, on the lane's stream
     c->frames_in_flight_hint = owner->lanes_attached + 1u;           // the owner and its lanes each keep a frame in flight
     const int rrc = spt_render_rows_device(c, cam, c->prog_w, c->prog_h, 0, c->prog_h, samps, seed, 0u, c->d_frame, nullptr);

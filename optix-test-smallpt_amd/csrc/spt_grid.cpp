@@ -16,7 +16,7 @@ inline float round_up(double v) { float f = (float)v; return (double)f < v ? std
 double reach_of(double r, double dmax)
 {
     const double E = std::ldexp(dmax * dmax + r * r, -17) + std::ldexp(2.25 * dmax * dmax, -19);
-    return std::sqrt(r * r + E) * (1.0 + 1e-12) + std::ldexp(dmax, -12);
+    return std::sqrt(r * r + E) * (1.0 + 1e-12) + std::ldexp(dmax, -11);      // + dgrid
 }
 
 // cells an interval [lo, hi] meets along one axis, clamped into the table (the device clamps its start cell the same way)
@@ -97,6 +97,9 @@ void build_sphere_grid(const float4* geom, const float* radius, uint32_t n, doub
                 const double c[3] = {geom[i].x, geom[i].y, geom[i].z};
                 for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a] - R); hi[a] = std::max(hi[a], c[a] + R); }
             }
+            // (an axis is at least 10^-3 of its coordinates' magnitude wide, see below: part of the box the ray test must admit --
+            // a thin table far from the origin, tests/sanitize/grid_main.cpp kind 8, had its box widened after Dmax was fixed)
+            for (int a = 0; a < 3; ++a) { const double mag = std::max(1.0, std::fabs(lo[a]) + std::fabs(hi[a])); hi[a] = std::max(hi[a], lo[a] + 1e-3 * mag); }
             return std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
         };
         for (int pass = 0; pass < 8; ++pass) {

@@ -17,11 +17,17 @@
 //       far below t_ok).  For every root t <= t_ok, with  E_j = 2^-17 (Dmax^2 + r_j^2) + 2^-19 (1.5 Dmax)^2  (128 u >= 101 u), the
 //       reported point lies within  sqrt(r_j^2 + E_j)  of c_j.
 //   (2) registration.  Sphere j is listed in every cell whose box is within R_j of c_j (Euclidean),  R_j = sqrt(r_j^2 + E_j) + dgrid,
-//       dgrid = 2^-12 Dmax; the grid box is the union of the cubes c_j +- R_j.
-//   (3) the walk.  tx/ty/tz = parameters at which the ray leaves the current cell, advanced by additions of cell / |d_a|
-//       (<= 3 * 128 steps; accumulated error <= 4 (steps + 4) u t, i.e. a position error below 2^-13 Dmax < dgrid).  For every true
+//       dgrid = 2^-11 Dmax; the grid box is the union of the cubes c_j +- R_j.
+//   (3) the walk.  tx/ty/tz = parameters at which the ray leaves the current cell along x / y / z, advanced by additions of cell / |d_a|.
+//       Where the walk believes a face to be differs from where it is by two terms, per axis: (i) the accumulated rounding of the exit
+//       parameters, <= 4 (steps + 4) u t with at most 3 * 128 steps and t <= 1.5 Dmax: 1.39e-4 Dmax; (ii) the rounding of the face
+//       coordinate b = gmin + i * cell itself, <= u (|gmin| + 2 extent): the builder keeps every axis' extent at >= 10^-3 of its
+//       coordinates' magnitude, and extent <= Dmax / 1.25, so <= 4.8e-5 Dmax.  Together 1.87e-4 Dmax per axis, 3.24e-4 Dmax as a distance
+//       (sqrt(3)) < dgrid = 4.88e-4 Dmax.  (Round 3 had dgrid = 2^-12 Dmax and counted term (i) only, and that at 2^-13 Dmax -- it is
+//       1.14 x that; the CPU harness never failed, but its scenes sat near the origin, where (ii) vanishes.  Round 4 doubles dgrid and
+//       adds scenes 300 ... 600 extents away from the origin and 128-cell-long tables to tests/sanitize/grid_main.cpp.)  For every true
 //       parameter t the walk is, at its computed time t, in a cell whose slab contains the true point up to that error in every
-//       axis (sqrt(3) 2^-13 Dmax < dgrid as a distance) -- so a cell within dgrid of the reported point p_j, in which j is listed, has been
+//       axis -- so a cell within dgrid of the reported point p_j, in which j is listed, has been
 //       visited once the computed exit time of the current cell is >= t_j.  The walk stops when that exit time reaches the current
 //       nearest t, or when it steps onto the one-cell border of sentinels around the table (no reported point lies outside the box,
 //       see (2)); the start cell is clamped into the table, which only adds cells.  Origins outside the box need no special case.

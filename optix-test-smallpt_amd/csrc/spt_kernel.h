@@ -109,6 +109,7 @@ extern "C" size_t spt_pool_stack_floats(uint32_t blocks, int pool);
 extern "C" size_t spt_pool_state_bytes(uint32_t blocks, int pool);
 extern "C" int spt_pool_max_spheres(void);
 extern "C" int spt_pool_default_slots(void);
+extern "C" int spt_pool_has_size(int pool);
 extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, int pool, hipStream_t stream);
 extern "C" hipError_t spt_k_selftest_range(int op, uint32_t first, uint32_t count, unsigned long long* d_mismatches, uint32_t* d_first_bad, hipStream_t stream);
 extern "C" hipError_t spt_k_accumulate(float* accum, const float* frame, size_t n, int clear, hipStream_t stream);

@@ -689,6 +689,15 @@ static hipError_t launch_pool_ng(const spt::KParams* K, uint32_t blocks, size_t 
     }
 }
 
+// pool sizes this build carries (spt_set_tuning refuses the others up front)
+extern "C" int spt_pool_has_size(int pool)
+{
+#ifdef SPT_POOL_SIZES
+    if (pool == 96 || pool == 192) return 1;
+#endif
+    return pool == 128 || pool == 144 || pool == 160;
+}
+
 extern "C" hipError_t spt_pool_launch(const spt::KParams* K, uint32_t blocks, int pool, hipStream_t stream)
 {
     const size_t lds = spt_pool_lds_bytes(K->n, pool);

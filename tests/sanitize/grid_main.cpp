@@ -103,6 +103,9 @@ Scene make_scene(int kind, uint32_t n, std::mt19937& rng)
         if (kind == 3) { c[0] = 50 + 3 * u(rng); c[1] = 40 + 3 * u(rng); c[2] = 80 + 3 * u(rng); }   // everything in a few cells
         if (kind == 4) { c[0] = 50; c[1] = 40; c[2] = 80; r = 0.1f + 0.01f * (float)s.geom.size(); }   // concentric shells
         if (kind == 5) { c[1] = 40; c[2] = 80; r = 0.3f; }                                             // a line of spheres: degenerate extent in y, z
+        if (kind == 6) { c[0] += 4e4f; c[1] -= 3e4f; c[2] += 6e4f; }                                   // the table 300 ... 600 extents away from the origin: the face coordinates' own rounding (spt_grid.h (3)(ii))
+        if (kind == 7 || kind == 8) { c[0] = 2000 * u(rng); c[1] = 40 + u(rng); c[2] = 80 + u(rng); r = 0.3f; }   // 128 cells along x, one or two along y and z
+        if (kind == 8) { c[0] += 9e5f; c[1] += 9e5f; c[2] -= 9e5f; }                                   // ... 450 extents away
         if (kind >= 2 && !s.geom.empty() && u(rng) < 0.05f) { const float4 g = s.geom[rng() % s.geom.size()]; c[0] = g.x; c[1] = g.y; c[2] = g.z; }
         add(s, c[0], c[1], c[2], r);
     }
@@ -204,7 +207,7 @@ int main(int argc, char** argv)
     const struct { int kind; uint32_t n; double density; size_t budget; } cases[] = {
         {0, 1024, 12, 150 * 1024}, {0, 1024, 3, 150 * 1024}, {0, 300, 40, 150 * 1024}, {1, 600, 12, 150 * 1024}, {2, 257, 12, 150 * 1024},
         {3, 200, 12, 150 * 1024}, {4, 120, 12, 150 * 1024}, {5, 64, 12, 150 * 1024}, {2, 25, 12, 150 * 1024}, {1, 4096, 12, 150 * 1024}, {0, 1024, 12, 12 * 1024},
-        {2, 1, 12, 150 * 1024}};
+        {2, 1, 12, 150 * 1024}, {6, 1024, 4, 150 * 1024}, {6, 300, 40, 150 * 1024}, {7, 2000, 4, 150 * 1024}, {8, 2000, 4, 150 * 1024}};
     for (const auto& cs : cases) {
         Scene s = make_scene(cs.kind, cs.n, rng);
         spt::SphereGrid g;

@@ -454,9 +454,9 @@ def test_kernel_watchdog_reports_instead_of_hanging(pkg):
 
 def test_cost_ordered_dispatch_changes_no_bit(pkg, oracle):
     """Pool kernel, cost-ordered dispatch (spt_api.cpp: a launch records how long each chunk of 64 tasks kept its wave busy, the next
-    launch of the same view hands the expensive chunks out first): the order is a permutation that keeps the partial last chunk last,
-    launches that use it -- same seed, another seed, a changed camera in between -- equal the oracle bit for bit with equal
-    bounce counts, and so does the static order (tuning bit 13)."""
+    launch of the same view AND seed hands the expensive chunks out first; another seed runs in the static order): every launch leaves an
+    order that is a permutation and keeps the partial last chunk last, and launches with and without it -- the same seed again, another
+    seed, a changed camera in between -- equal the oracle bit for bit with equal bounce counts, and so does tuning bit 13 (never ordered)."""
     r = pkg.Renderer(0)
     r.set_watchdog(20.0)
     r.set_scene(pkg.cornell9())
@@ -513,6 +513,9 @@ def test_error_behaviour(pkg):
     t = torch.empty((4, 8, 3), dtype=torch.float32, device="cuda:0")
     with pytest.raises(pkg.SptError, match="outside image"):
         r.render_rows_device(t, 8, 8, 6, 4, 1)
+    with pytest.raises(pkg.SptError, match="no pool kernel with 96 slots"):      # a pool size only -DSPT_POOL_SIZES builds carry: refused up front,
+        r.set_tuning(0, 1 << 11)                                                 # not as "invalid argument" at the next launch
+    r.render(8, 8, 1)                                                            # (the refused word changed nothing)
     r.close()
 
 
