@@ -29,6 +29,8 @@ def run(name, scene, w, h, samps, band=None, oracle_rows=None, reps=2):
     r.set_watchdog(120.0)
     r.set_scene(scene)
     n = len(scene)
+    if n <= 24:
+        r.set_tuning(0, 0x2000)          # pool kernel: static dispatch order, what a one-shot render gets (the repetitions below use one seed)
     begin, count = band if band else (0, h)
     out = torch.empty((count, w, 3), dtype=torch.float32, device="cuda:0")
     best = None
