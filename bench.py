@@ -164,8 +164,21 @@ def extra_sphere_config(pkg, label, scene, samps, reps=3):
         tests = d[1] / rays + min(always, 1024)
         fl = 45.0 + bbar * (17.0 * tests + 100.0)
         ach = st["samples"] * fl / (k_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of this kernel on this configuration, from the committed PMC passes (constants, not measured in this run)
+        traffic, prov = None, None
+        pj_path = os.path.join(ROOT, "profiles", "pmc_config5.json")
+        if n == 1024 and samps == 256 and os.path.exists(pj_path):
+            try:
+                pj = json.load(open(pj_path))
+                if pj.get("kernel", "").endswith(KERNEL_NAMES.get(kern, kern).split("::")[-1]):
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    prov = {"file": "profiles/pmc_config5.json", "kernel": pj.get("kernel"), "measured_at_kernel_ms": pj.get("kernel_ms"), "commit": pj.get("commit"),
+                            "note": "FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes: the slots' path state (96 B per slot in global memory, "
+                                    "75 MB per launch, beyond the L2) goes through the fabric once per bounce; Infinity-Cache hits are counted"}
+            except Exception:
+                traffic, prov = None, None
         res["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-                           "traffic": None, "flops_per_sample": round(fl, 1), "sphere_tests_per_query": round(tests, 2),
+                           "traffic": traffic, "from_committed_profile": prov, "flops_per_sample": round(fl, 1), "sphere_tests_per_query": round(tests, 2),
                            "cell_steps_per_query": round(d[0] / rays, 2), "exhaustive_loop_rays": d[4],
                            "exhaustive_equivalent_tflops": round(st["samples"] * fl_formula / (k_ms * 1e-3) / 1e12, 2),
                            "note": "algorithmic flops = 45 + B (17 T + 100) with T = sphere tests executed per closest-hit query (uniform grid, "

@@ -1,6 +1,6 @@
 """Turns a tools/prof_pmc.sh summary (gpurun_out/<tag>_summary.txt) into profiles/pmc_latest.json, the PMC-derived
 constants bench.py prints beside its live timing (roofline.traffic and roofline.decomposition).
-usage: python tools/pmc_to_json.py gpurun_out/r02_pmc_summary.txt [kernel-substring] [kernel_ms of the profiled launches]"""
+usage: python tools/pmc_to_json.py gpurun_out/r02_pmc_summary.txt [kernel-substring] [kernel_ms of the profiled launches] [output name under profiles/]"""
 import subprocess
 import json
 import os
@@ -19,7 +19,7 @@ for line in open(src):
         m = re.match(r"\s+(\S+)\s+n=(\d+) mean=(\S+)", line)
         if m and cur:
             sec[cur][m.group(1)] = float(m.group(3))
-name = next(k for k in sec if want in k)
+name = next(k for k in sec if want in k and "<true>" not in k.replace("finalize<true>", ""))   # (not the instrumented build)
 c = sec[name]
 out = {
     "_source": f"{os.path.relpath(src, ROOT)}: rocprofv3 --pmc passes (tools/prof_pmc.sh; FETCH_SIZE and WRITE_SIZE in separate passes) of "
@@ -39,5 +39,5 @@ out = {
     "kernel_ms": float(sys.argv[3]) if len(sys.argv) > 3 else (c["GRBM_GUI_ACTIVE"] / (8 * 2.4e6) if "GRBM_GUI_ACTIVE" in c else None),
     "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None,
 }
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", sys.argv[4] if len(sys.argv) > 4 else "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -62,7 +62,7 @@ def run(name, scene, w, h, samps, band=None, oracle_rows=None, reps=2):
             worst = max(worst, rel_l2(img[rr:rr + 1], ref))
             exact &= bool(np.array_equal(img[rr:rr + 1], ref))
             checked += 1
-    grid = r.last_kernel() == "grid"      # the grid kernel does not test every sphere: SURVEY 8(d)'s formula prices the exhaustive loop, not what ran
+    grid = r.last_kernel() in ("grid", "gpool")      # the grid kernels do not test every sphere: SURVEY 8(d)'s formula prices the exhaustive loop, not what ran
     row = {"config": name, "spheres": n, "image": f"{w}x{h}", "rows": f"{begin}..{begin + count - 1}", "spp": 4 * samps,
            "samples": st["samples"], "wall_ms": round(wall * 1e3, 2), "kernel_ms": round(st["kernel_ms"], 2),
            "finalize_ms": round(st["finalize_ms"], 4),
