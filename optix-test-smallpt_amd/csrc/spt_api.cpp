@@ -63,7 +63,7 @@ struct spt_ctx {
     int sphere_accel = SPT_ACCEL_GRID;
     // uniform grid over the sphere table (spt_grid.h): built in spt_set_scene for tables above the pool kernel's limit
     bool grid_ready = false;         // the tables below belong to the current sphere scene and the scene qualifies
-    bool grid_global = false;        // ... and stay in global memory (tables beyond one CU's LDS): spt_grid.hip GLOBAL_TABLES
+    int grid_global = 0;             // ... 1: every table stays in global memory, 2: the sphere records do, the grid is staged in LDS (spt_grid.hip WHERE)
     spt::GridParams grid{};
     uint32_t* d_grid_cells = nullptr; uint16_t* d_grid_refs = nullptr; uint32_t* d_grid_always = nullptr;
     std::string grid_why;            // why the current scene does not run on the grid kernel
@@ -100,7 +100,7 @@ struct spt_ctx {
     // grid kernels: 0 = wave-private path pools (spt_gpool.hip) whenever the LDS has room for them, 1 = lanes own their path (spt_grid.hip);
     // pool geometry {slots per wave, begun walks per wave, drain, smallest batch, walk iterations behind a batch's loads} (spt_set_grid_pools)
     int grid_lane_owned = 0;
-    bool grid_force_global = false;
+    int grid_force_global = 0;
     uint32_t gq[5] = {192u, 96u, 24u, 32u, 4u};
     // pool kernel, cost-ordered dispatch (spt_kernel.h KParams::chunk_order): tables of the last pool launch and the view they belong to
     uint32_t* d_chunk_tables = nullptr;   // order[cap] | clock[2 * cap] | 512 words of the sorting kernels
@@ -239,7 +239,7 @@ int spt_set_grid_pools(spt_ctx* c, int lane_owned, uint32_t slots, uint32_t read
     if (slots > 256u || (slots & 15u) || ready > 0xFFFFu || drain > 64u)
         return c->fail("spt_set_grid_pools: slots must be a multiple of 16 up to 256, ready <= 65535, drain <= 64");
     c->grid_lane_owned = lane_owned ? 1 : 0;
-    c->grid_force_global = lane_owned == 2;                      // (A/B: tables in global memory although they would fit the LDS; read by the next spt_set_scene)
+    c->grid_force_global = lane_owned >= 2 ? lane_owned - 1 : 0;   // 2: every table in global memory, 3: the sphere records only                      // (A/B: tables in global memory although they would fit the LDS; read by the next spt_set_scene)
     const uint32_t def[5] = {192u, 96u, 24u, 32u, 4u}, in[5] = {slots, ready & ~3u, drain, min_batch, walk_iters};
     for (int i = 0; i < 5; ++i) c->gq[i] = in[i] ? in[i] : def[i];
     return 0;
@@ -365,8 +365,8 @@ static int build_sphere_grid_tables(spt_ctx* c)
     spt::SphereGrid g;
     const uint32_t dsel = (c->variant >> 24) & 0xFFu;
     const bool records_fit = (size_t)c->n * 16u + 8192u <= (size_t)150 * 1024;
-    c->grid_global = false;
-    if (records_fit && !c->grid_force_global) spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, grid_table_budget(c->n), g);
+    c->grid_global = 0;
+    if (records_fit && c->grid_force_global == 0) spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, grid_table_budget(c->n), g);
     // (an LDS grid that had to shrink below a quarter of a cell per sphere to fit -- from about 6 500 random spheres on -- tests too many
     // spheres per cell: 8 000 spheres, 4 x 4 x 7 cells: 336 Msamples/s from LDS against 596 from global memory at the full resolution;
     // 6 000 spheres, 0.36 cells per sphere: 888 against 666; profiles/r04_big_tables.txt)
@@ -375,10 +375,20 @@ static int build_sphere_grid_tables(spt_ctx* c)
         if (interior < 0.25 * in_grid_n) g = spt::SphereGrid();
     }
     if (!g.usable) {
-        if (c->n > kGridGlobalMax) { c->grid_why = records_fit ? g.why : "sphere records alone exceed the LDS, and the table is beyond the size up to which the global-memory grid beats the hierarchy"; return 0; }
+        const std::string lds_why = g.why;
+        if (c->n > 0xFFFFu) { c->grid_why = "more spheres than the grid's 16-bit references address"; return 0; }
+        // the sphere records in global memory and the grid in LDS (two of the walk's three lookups per sphere stay LDS reads), if a grid of
+        // at least a quarter of a cell per sphere fits there; else everything in global memory at the full resolution, up to kGridGlobalMax
         g = spt::SphereGrid();
-        spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, (size_t)256 << 20, g);
-        c->grid_global = true;
+        if (c->grid_force_global != 1) spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, (size_t)150 * 1024, g);
+        c->grid_global = 2;
+        const double interior = g.usable ? (double)g.P.dim[0] * g.P.dim[1] * g.P.dim[2] : 0.0;
+        if (!g.usable || interior < 0.25 * ((double)c->n - (double)g.always.size())) {
+            if (c->n > kGridGlobalMax) { c->grid_why = records_fit ? lds_why : "sphere records alone exceed the LDS, and the table is beyond the size up to which the global-memory grid beats the hierarchy"; return 0; }
+            g = spt::SphereGrid();
+            spt::build_sphere_grid(c->h_geom.data(), c->h_radius.data(), c->n, dsel ? (double)dsel : 4.0, (size_t)256 << 20, g);
+            c->grid_global = 1;
+        }
     }
     if (!g.usable) { c->grid_why = g.why; return 0; }
     // A cell that lists a third of the table means nearly everything shares a cell (the extent is set by a few large spheres that
@@ -937,7 +947,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));
         SPT_HIP(c, spt_grid_launch(&P, &c->grid, c->d_grid_cells, c->d_grid_refs, c->d_grid_always, blocks, threads, lsel ? lsel - 1u : 16u, (c->variant & 0x100u) ? 1 : 0,
-                                   c->grid_global ? 1 : 0, st));
+                                   c->grid_global, st));
         SPT_HIP(c, hipEventRecord(c->ev_mid, st));
         SPT_HIP(c, spt_k_finalize(c->d_cells, static_cast<float*>(d_out_rgb), (uint32_t)npix, scale, (flags & SPT_FLAG_NORMALISE) ? 1 : 0, nb, st));
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));

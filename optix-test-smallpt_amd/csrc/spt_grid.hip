@@ -51,21 +51,24 @@ struct GPath { f3 o, d, w; uint32_t depth, branch, rbase; };
 // GLOBAL_TABLES (round 4): sphere records, cell headers and references are read where they lie in global memory (L2 / Infinity-Cache
 // resident: 16 384 spheres are 0.26 MB of records + 0.5 MB of grid) instead of one CU's LDS -- tables beyond the LDS keep the grid (the same
 // walk, the same proof, spt_grid.h) instead of falling to the one-lane-per-path hierarchy.  The always-tested list is read from its own array.
-template <bool STATS, bool GLOBAL_TABLES>
+// WHERE = 2: the sphere records stay in global memory, the cell headers and references -- two of the walk's three lookups per sphere --
+// in LDS: tables whose records alone exceed the LDS but whose grid fits it.
+template <bool STATS, int WHERE>
 __global__ __launch_bounds__(kGridBlock) void gridkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
                                                          const uint16_t* __restrict__ g_refs, const uint32_t* __restrict__ g_always, uint32_t leave_q)
 {
-    extern __shared__ float4 s_lds_geom[];                       // n sphere records, then the grid tables (not GLOBAL_TABLES)
-    uint32_t* const s_lds_cells = reinterpret_cast<uint32_t*>(s_lds_geom + (G.n ? G.n : 1u));
+    constexpr bool GLOBAL_TABLES = WHERE == 1, GLOBAL_GEOM = WHERE != 0;
+    extern __shared__ float4 s_lds_geom[];                       // n sphere records (WHERE 0), then the grid tables (WHERE 0, 2)
+    uint32_t* const s_lds_cells = reinterpret_cast<uint32_t*>(s_lds_geom + (GLOBAL_GEOM ? 0u : (G.n ? G.n : 1u)));
     uint16_t* const s_lds_refs = reinterpret_cast<uint16_t*>(s_lds_cells + G.ncells);   // nrefs cell references, then the always-tested list, one spare
+    if (!GLOBAL_GEOM) for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) s_lds_geom[i] = K.geom[i];
     if (!GLOBAL_TABLES) {
-        for (uint32_t i = threadIdx.x; i < G.n; i += blockDim.x) s_lds_geom[i] = K.geom[i];
         for (uint32_t i = threadIdx.x; i < G.ncells; i += blockDim.x) s_lds_cells[i] = g_cells[i];
         for (uint32_t i = threadIdx.x; i < G.nrefs; i += blockDim.x) s_lds_refs[i] = g_refs[i];
         for (uint32_t i = threadIdx.x; i <= G.nalways; i += blockDim.x) s_lds_refs[G.nrefs + i] = i < G.nalways ? (uint16_t)g_always[i] : (uint16_t)0;
     }
     // (the template argument decides the address space at compile time: LDS reads or global loads, never generic ones)
-    auto geom_at = [&](uint32_t i) -> float4 { return GLOBAL_TABLES ? K.geom[i] : s_lds_geom[i]; };
+    auto geom_at = [&](uint32_t i) -> float4 { return GLOBAL_GEOM ? K.geom[i] : s_lds_geom[i]; };
     auto cell_at = [&](uint32_t ci) -> uint32_t { return GLOBAL_TABLES ? g_cells[ci] : s_lds_cells[ci]; };
     auto ref_at = [&](uint32_t k) -> uint32_t { return GLOBAL_TABLES ? (uint32_t)g_refs[k] : (uint32_t)s_lds_refs[k]; };
     auto always_at = [&](uint32_t k) -> uint32_t { return GLOBAL_TABLES ? g_always[k] : (uint32_t)s_lds_refs[G.nrefs + k]; };
@@ -444,21 +447,29 @@ extern "C" size_t spt_grid_lds_bytes(const spt::GridParams* G)
 extern "C" int spt_grid_block_threads(void) { return spt::kGridBlock; }
 extern "C" size_t spt_grid_stack_floats(uint32_t blocks, uint32_t threads) { return (size_t)blocks * threads * 36u; }
 
-extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
-                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, int global_tables, hipStream_t stream)
+// LDS of the grid tables alone (WHERE = 2: the sphere records stay in global memory)
+extern "C" size_t spt_grid_lds_bytes_tables(const spt::GridParams* G)
 {
-    if (threads == 0 || threads > (uint32_t)spt::kGridBlock || (threads & 63u)) return hipErrorInvalidValue;
-    const size_t lds = global_tables ? 0 : spt_grid_lds_bytes(G);
-    const void* fn = global_tables ? (stats ? reinterpret_cast<const void*>(&spt::gridkernel<true, true>) : reinterpret_cast<const void*>(&spt::gridkernel<false, true>))
-                                   : (stats ? reinterpret_cast<const void*>(&spt::gridkernel<true, false>) : reinterpret_cast<const void*>(&spt::gridkernel<false, false>));
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return (size_t)G->ncells * 4u + (((size_t)G->nrefs + G->nalways + 2u) / 2u) * 4u + 16u;
+}
+
+template <bool STATS, int WHERE>
+static hipError_t launch_grid(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs, const uint32_t* d_always,
+                              uint32_t blocks, uint32_t threads, uint32_t leave_q, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spt::gridkernel<STATS, WHERE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (global_tables) {
-        if (stats) hipLaunchKernelGGL((spt::gridkernel<true, true>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
-        else hipLaunchKernelGGL((spt::gridkernel<false, true>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
-    } else {
-        if (stats) hipLaunchKernelGGL((spt::gridkernel<true, false>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
-        else hipLaunchKernelGGL((spt::gridkernel<false, false>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
-    }
+    hipLaunchKernelGGL((spt::gridkernel<STATS, WHERE>), dim3(blocks), dim3(threads), lds, stream, *K, *G, d_cells, d_refs, d_always, leave_q);
     return hipGetLastError();
+}
+
+// where: 0 = every table in LDS, 1 = every table in global memory, 2 = sphere records in global memory, cell headers and references in LDS
+extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
+                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, int where, hipStream_t stream)
+{
+    if (threads == 0 || threads > (uint32_t)spt::kGridBlock || (threads & 63u) || where < 0 || where > 2) return hipErrorInvalidValue;
+    const size_t lds = where == 1 ? 0 : (where == 2 ? spt_grid_lds_bytes_tables(G) : spt_grid_lds_bytes(G));
+    if (where == 0) return stats ? launch_grid<true, 0>(K, G, d_cells, d_refs, d_always, blocks, threads, leave_q, lds, stream) : launch_grid<false, 0>(K, G, d_cells, d_refs, d_always, blocks, threads, leave_q, lds, stream);
+    if (where == 1) return stats ? launch_grid<true, 1>(K, G, d_cells, d_refs, d_always, blocks, threads, leave_q, lds, stream) : launch_grid<false, 1>(K, G, d_cells, d_refs, d_always, blocks, threads, leave_q, lds, stream);
+    return stats ? launch_grid<true, 2>(K, G, d_cells, d_refs, d_always, blocks, threads, leave_q, lds, stream) : launch_grid<false, 2>(K, G, d_cells, d_refs, d_always, blocks, threads, leave_q, lds, stream);
 }

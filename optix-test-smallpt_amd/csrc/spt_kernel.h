@@ -91,7 +91,8 @@ extern "C" size_t spt_grid_lds_bytes(const spt::GridParams* G);
 extern "C" int spt_grid_block_threads(void);
 extern "C" size_t spt_grid_stack_floats(uint32_t blocks, uint32_t threads);
 extern "C" hipError_t spt_grid_launch(const spt::KParams* K, const spt::GridParams* G, const uint32_t* d_cells, const uint16_t* d_refs,
-                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, int global_tables, hipStream_t stream);
+                                      const uint32_t* d_always, uint32_t blocks, uint32_t threads, uint32_t leave_q, int stats, int where, hipStream_t stream);
+extern "C" size_t spt_grid_lds_bytes_tables(const spt::GridParams* G);
 extern "C" size_t spt_mesh_lds_bytes(int bvh);
 extern "C" size_t spt_mesh_stack_floats(uint32_t blocks);
 extern "C" hipError_t spt_mesh_launch(const spt::KParams* K, const spt::MParams* M, uint32_t blocks, hipStream_t stream);

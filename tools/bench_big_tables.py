@@ -17,12 +17,15 @@ r.set_watchdog(120.0)
 for n in ns:
     sc = pkg.random_spheres(n, 7)
     ref = orc.render(sc, w, h, samps, seed=0, normalise=True, row_begin=300, row_count=1)[0]
-    for accel, name in ((pkg.ACCEL_GRID, "grid"), (pkg.ACCEL_GRID, "grid, tables forced into global memory"), (pkg.ACCEL_BVH, "hierarchy")):
-        if "forced" in name and "--force-global" not in sys.argv:
+    for accel, name in ((pkg.ACCEL_GRID, "grid"), (pkg.ACCEL_GRID, "grid, tables forced into global memory"), (pkg.ACCEL_GRID, "grid, records forced into global memory (grid in LDS)"),
+                        (pkg.ACCEL_BVH, "hierarchy")):
+        if "tables forced" in name and "--force-global" not in sys.argv:
+            continue
+        if "records forced" in name and "--force-hybrid" not in sys.argv:
             continue
         for per_cu, tsel in (geoms if accel == pkg.ACCEL_GRID else [(0, 0)]):
             r.set_tuning(per_cu, tsel << 13)
-            r.set_grid_pools(lane_owned=2 if "forced" in name else 0)
+            r.set_grid_pools(lane_owned=2 if "tables forced" in name else (3 if "records forced" in name else 0))
             r.set_sphere_accel(accel)
             r.set_scene(sc)
             best = None
