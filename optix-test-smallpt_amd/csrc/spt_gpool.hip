@@ -8,7 +8,7 @@
 //
 //   * every WAVE owns S path slots.  A slot is one task (one D9 block of a jitter cell, smallpt.cpp:299-309) with at most one path
 //     in flight, so emission events are accumulated in the order of D9.  A slot's state -- origin, direction, weight, RNG keys, depth,
-//     task, block sum: 96 bytes -- lives in GLOBAL memory (wave-private lines, L2 / Infinity-Cache resident); LDS holds the grid
+//     task, block sum: 96 bytes in a 128-byte line -- lives in GLOBAL memory (wave-private lines, L2 / Infinity-Cache resident); LDS holds the grid
 //     tables (one copy per CU, as in spt_grid.hip), per wave a stack of R begun walks (READY, 56 bytes each) and byte lists of slot ids.
 //   * the 64 lanes of the wave are WALKERS: a lane holds one walk in registers (ray, exit parameters, cell, nearest key) and runs
 //     the fused body { leave the cell if all its spheres are tested; test the next sphere } until its walk ends.  Finished lanes
@@ -31,8 +31,14 @@ namespace spt {
 constexpr int kQBlock = 1024;                                    // threads per workgroup (one workgroup per CU shares the LDS tables)
 constexpr uint32_t kQEpsBias = 0x38D1B717u + 1u;                 // bits(1e-4f) + 1
 constexpr uint32_t kQInfKey = 0x60AD78ECu - kQEpsBias;           // key of 1e20f (maths.h:16)
-constexpr uint32_t kQSlotBytes = 96;                             // = 16 kQSlotF4
-constexpr int kQSlotF4 = 6;                                      // float4 per slot in global memory
+#ifndef QX_SLOT_F4
+#define QX_SLOT_F4 8
+#endif
+// float4 per slot in global memory: 6 are used, 8 make a slot exactly one 128-byte line.  At 96 bytes half the slots straddle two lines and
+// a batch fetched 1.5 lines per slot through the fabric (the 75 MB of slots are beyond the L2): 128-byte slots are 4.6 % faster (383 -> 366 ms
+// on config 5) although the working set grows to 100 MB -- the kernel feels its 5 TB/s of slot traffic.
+constexpr int kQSlotF4 = QX_SLOT_F4;
+constexpr uint32_t kQSlotBytes = 16u * kQSlotF4;
 constexpr uint32_t kQFew = 4u;                                   // a batch that leaves at most this many rays answers them with the whole wave
 constexpr uint32_t kQFin = 0xFFFFu;                              // staged header of a border cell / the walker's cur when its walk has ended
 constexpr int kQStackF4 = 4;                                     // one pending child = one 64-byte line
