@@ -108,7 +108,10 @@ __device__ __forceinline__ uint32_t pack_q(uint32_t depth, uint32_t branchf, uin
 
 enum { QC_GEN = 0, QC_HIT = 1, QC_HITR = 2 };
 
-// Global slot record (6 float4): Q0 {o.xyz, t_ok}  Q1 {d.xyz, packed}  Q2 {w.xyz, k1}  Q3 {rbase, task + 1, next sample, -}
+// Global slot record (6 float4 of a 128-byte line).  What every bounce reads and writes sits in the line's FIRST 64-byte sector:
+//   Q0 {o.xyz, t_ok}  Q1 {d.xyz, packed}  Q2 {w.xyz, k1}  Q3 {rbase, -, near key, near index};
+// what only the GEN batches (one in nine) and emissive hits touch in the second: Q4 {task + 1, next sample, -, -}  Q5 {block sum xyz, -}.
+// (old layout, for the record:) Q3 {rbase, task + 1, next sample, -}
 //                                Q4 {near key, near index, -, -}  Q5 {block sum xyz, -}
 template <bool STATS>
 __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const GridParams G, const uint32_t* __restrict__ g_cells,
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
     for (uint32_t s = lane; s < S; s += 64u) {
         LGN[s] = (uint8_t)s;
         slots[s * kQSlotF4 + 1] = make_float4(0.f, 0.f, 1.f, __uint_as_float(0u));
-        slots[s * kQSlotF4 + 3] = make_float4(0.f, __uint_as_float(0u), __uint_as_float(0u), 0.f);
+        slots[s * kQSlotF4 + 4] = make_float4(__uint_as_float(0u), __uint_as_float(0u), 0.f, 0.f);
     }
     __syncthreads();
 
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             if (cur == kQFin) {
                 cur = 1u;                                        // (end is 0 already)
                 const uint32_t inst = near_i - gb16;
-                *reinterpret_cast<uint2*>(slot_bytes + wslot * kQSlotBytes + 64u) = make_uint2(near_key, inst);
+                *reinterpret_cast<uint2*>(slot_bytes + wslot * kQSlotBytes + 56u) = make_uint2(near_key, inst);
                 hcls = (near_key != kQInfKey && (__float_as_uint(s_mat[inst].w) & 3u) == 2u) ? 2u : 1u;
             }
             const unsigned long long mh = __ballot(hcls == 1u), mr = __ballot(hcls == 2u);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
         uint32_t slot = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, __builtin_inff()), q1 = make_float4(0.f, 0.f, 1.f, 0.f), q2 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 q3 = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 q4 = make_uint2(kQInfKey, 0u);
+        uint2 q4 = make_uint2(kQInfKey, 0u), qt = make_uint2(0u, 0u);
         if (run_batch) {
             idle = false;
             if (cls == QC_GEN) { nG -= b; if (valid) slot = LGN[nG + lane]; }
@@ -278,8 +281,10 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             const float4* const lq = slots + slot * kQSlotF4;
             // (every lane loads -- idle lanes read slot 0, never use it --: a merge with default values would need the data at once;
             // and every class loads the five rows (a GEN batch needs two of them): a merge at a branch would, too)
-            q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q4 = reinterpret_cast<const uint2*>(lq + 4)[0];
-            { const float* const l3 = reinterpret_cast<const float*>(lq + 3); q3.x = l3[0]; q3.y = l3[1]; q3.z = l3[2]; }   // (a register loaded and never read would be reused by the walk: a wait)
+            q0 = lq[0]; q1 = lq[1]; q2 = lq[2];
+            q3.x = reinterpret_cast<const float*>(lq + 3)[0];                             // rbase (a register loaded and never read would be reused by the walk: a wait)
+            q4 = reinterpret_cast<const uint2*>(lq + 3)[1];                               // near key, near index
+            qt = reinterpret_cast<const uint2*>(lq + 4)[0];                               // task + 1, next sample (GEN batches)
         }
 
         if (nAct != 0u) {
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
         if (cls == QC_GEN) {
             // ================= GEN: continue the slot's task (smallpt.cpp:304-340, :252 pop) =================
             sp = __float_as_uint(q1.w) >> 30;
-            uint32_t task1 = __float_as_uint(q3.y), snext = __float_as_uint(q3.z);     // task + 1 (0: the slot has no task)
+            uint32_t task1 = qt.x, snext = qt.y;                                       // task + 1 (0: the slot has no task)
             uint32_t send = 0;
             if (task1 != 0u) {
                 const uint32_t sbeg = ((task1 - 1u) & ((1u << K.nb_log2) - 1u)) * K.sb;
@@ -452,7 +457,8 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
             }
             if (has_ray) {
                 sq[2] = make_float4(w.x, w.y, w.z, __uint_as_float(k1));
-                sq[3] = make_float4(__uint_as_float(rbase), __uint_as_float(task1), __uint_as_float(snext), 0.f);
+                sq[3].x = __uint_as_float(rbase);
+                reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(task1, snext);
             }
             QSTAMP(2)
         } else {
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                 }
                 if (requeue != 0u) {                             // the other class's batch shades it: the answer is final (t_ok = inf)
                     sq[0] = make_float4(q0.x, q0.y, q0.z, __builtin_inff());
-                    reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(hkey, inst);
+                    reinterpret_cast<uint2*>(sq + 3)[1] = make_uint2(hkey, inst);
                 }
             }
             const bool live = valid && requeue == 0u;
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(kQBlock) void gpoolkernel(const KParams K, const Gr
                     }
                 }
                 if (has_ray && !ok) {
-                    reinterpret_cast<uint2*>(sq + 4)[0] = make_uint2(bkey, bi - gb16);
+                    reinterpret_cast<uint2*>(sq + 3)[1] = make_uint2(bkey, bi - gb16);
                     requeue = (bkey != kQInfKey && (__float_as_uint(s_mat[bi - gb16].w) & 3u) == 2u) ? 2u : 1u;
                 }
             }
