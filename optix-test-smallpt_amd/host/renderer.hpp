@@ -42,7 +42,7 @@ public:
     {
         std::vector<float3> out(imageWidth * imageHeight);
         check(spt_render(ctx_, &camera, (uint32_t)imageWidth, (uint32_t)imageHeight, (uint32_t)sampleCountPerJitterCell,
-                         (uint64_t)seed, normalise ? SPT_FLAG_NORMALISE : 0u, reinterpret_cast<float*>(out.data()), &stats_));
+                         (uint64_t)seed, (normalise ? SPT_FLAG_NORMALISE : 0u) | (oneShot_ ? SPT_FLAG_ONE_SHOT : 0u), reinterpret_cast<float*>(out.data()), &stats_));
         return out;
     }
 
@@ -101,6 +101,8 @@ public:
 
     const spt_stats& stats() const { return stats_; }
     spt_ctx* handle() { return ctx_; }
+    // a caller that renders a view once (cpuRender, smallpt.cpp:269-379): the launch records no dispatch order for a repetition (SPT_FLAG_ONE_SHOT)
+    void setOneShot(bool on) { oneShot_ = on; }
 
 private:
     void check(int rc)
@@ -109,6 +111,7 @@ private:
     }
     spt_ctx* ctx_ = nullptr;
     spt_stats stats_{};
+    bool oneShot_ = false;
 };
 
 // The same call spread over the GPUs of one node (include/smallpt_mi355x_multi.h): one host thread + context per
@@ -154,10 +157,11 @@ public:
     {
         std::vector<float3> out(imageWidth * imageHeight);
         check(spt_multi_render(m_, &camera, (uint32_t)imageWidth, (uint32_t)imageHeight, (uint32_t)sampleCountPerJitterCell,
-                               (uint64_t)seed, normalise ? SPT_FLAG_NORMALISE : 0u, reinterpret_cast<float*>(out.data()), &stats_));
+                               (uint64_t)seed, (normalise ? SPT_FLAG_NORMALISE : 0u) | (oneShot_ ? SPT_FLAG_ONE_SHOT : 0u), reinterpret_cast<float*>(out.data()), &stats_));
         return out;
     }
     const spt_multi_stats& stats() const { return stats_; }
+    void setOneShot(bool on) { oneShot_ = on; }                  // as Renderer::setOneShot, on every device
     // the render thread's loop over all devices (smallpt.cpp:895-942; spt_multi_progressive_*): accumBuffer on the root device
     void progressiveBegin(size_t imageWidth, size_t imageHeight)
     {
@@ -184,6 +188,7 @@ private:
     size_t pw_ = 0, ph_ = 0;
     spt_multi* m_ = nullptr;
     spt_multi_stats stats_{};
+    bool oneShot_ = false;
 };
 
 }  // namespace spt_host

@@ -184,6 +184,7 @@ int main(int argc, char* argv[])
         }
         Renderer renderer(device);
         upload(renderer);
+        renderer.setOneShot(true);                               // cpuRender renders its view once
         std::vector<float3> c = renderer.render(cam, (size_t)w, (size_t)h, (size_t)samps, (size_t)seed, /*normalise=*/true);
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
         const spt_stats& st = renderer.stats();
