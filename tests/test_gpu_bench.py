@@ -28,6 +28,11 @@ def test_bench_json_line_contract():
         assert k in r, k
     assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert j["value"] > 100 and j["ms_per_step"] > 0
+    # round 4: a new seed every step (said in the workload), the same-seed re-render beside `value`, provenance of the PMC constants
+    assert "seed = step index" in j["config"]["workload"]
+    rr = j["rerender_same_seed"]
+    assert len(rr["kernel_ms_per_launch"]) == 4 and rr["value"] > 100
+    assert "from_committed_profile" in r and "kernel_ms_per_step" in r and len(r["kernel_ms_per_step"]) == 2
 
 
 @pytest.mark.gpu
