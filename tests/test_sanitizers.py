@@ -83,3 +83,15 @@ def test_sphere_grid_builder_and_walk_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "mismatches 0," in r.stdout and "grid harness ok" in r.stdout
+
+
+def test_task_dealing_is_a_bijection(tmp_path):
+    """csrc/spt_deal.h deal_task (which task a queue position stands for in the grid-pool, grid, mega and mesh kernels): every task id exactly
+    once over the valid positions, "no task" for the holes of the last stride, for positions at or beyond the end and for the grid-pool
+    kernel's nothing-left position -- the property whose violation (a sentinel inside the valid range) made a launch loop for ever
+    once during round 4 (tests/sanitize/deal_main.cpp, under ASan + UBSan)."""
+    exe = tmp_path / "deal_main"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "sanitize", "deal_main.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "deal_task ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
