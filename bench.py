@@ -376,11 +376,11 @@ def main():
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, samples, bounces = float(mx[0]), float(sm[1]), float(sm[2])
     # Beside the timed steps, outside the timed region: the SAME seed rendered again and again, which the library's cost-ordered dispatch
-    # turns into its best case (each launch starts the chunks that were expensive in the previous one first; converges over 2-3 launches).
+    # turns into its best case (each launch starts the chunks that were expensive in the previous one first; a launch records only when it repeats its predecessor, so the order starts with the third launch and converges over 2-3 more).
     rerender = None
     if world == 1:
         ks = []
-        for _ in range(4):
+        for _ in range(5):                       # 1: static, 2: static + records (it repeats its predecessor), 3-5: ordered
             _, st1 = step(fixed_seed=0xC0FFEE)
             ks.append(st1["kernel_ms"])
         rerender = {"kernel_ms_per_launch": [round(k, 3) for k in ks], "kernel_ms": round(ks[-1], 3),

@@ -200,6 +200,8 @@ int  spt_render(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,
  * Scheduling only (never the result): for tables of <= 24 spheres and >= 16 samples per cell a context remembers how long each group
  * of sample blocks took in its last launch, and a launch of the same scene, camera, image, band, sample count AND SEED starts the
  * expensive ones first: re-rendering a view is ~4 % shorter at 1024 spp than rendering it the first time (79.4 -> 76.3 ms on config 2).
+ * A launch records those times only when it repeats its predecessor (recording costs 0.6 ms of such a launch), so the gain starts with the
+ * third identical launch.
  * Another seed of the view runs in the static order like a first launch -- measured, the previous seed's order makes it 1 % SLOWER
  * (profiles/r04_cost_order_seeds.txt; round 3 claimed the gain for any seed without having stepped it).  SPT_FLAG_ONE_SHOT opts a launch out. */
 int  spt_render_rows_device(spt_ctx* ctx, const spt_camera* cam, uint32_t w, uint32_t h,

@@ -106,7 +106,8 @@ struct spt_ctx {
     uint32_t* d_chunk_tables = nullptr;   // order[cap] | clock[2 * cap] | 512 words of the sorting kernels
     size_t chunk_cap = 0;
     bool order_valid = false;
-    std::vector<unsigned char> order_key;  // camera, image, band, samples, scene generation: an identical next launch reuses the order
+    std::vector<unsigned char> order_key;  // camera, image, band, samples, scene generation, seed: an identical next launch reuses the order
+    std::vector<unsigned char> last_pool_key;   // ... of the last pool launch, recorded or not: a launch records only when it repeats its predecessor
     uint64_t scene_gen = 0;
     uint32_t last_nchunks = 0;             // chunks of the launch the order table was derived from (0: that launch recorded none)
     hipEvent_t ev_order = nullptr;         // the order kernel of the last pool launch has run (the next launch may come on another stream)
@@ -1049,8 +1050,11 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         // wrong at the granularity of a chunk -- 80.4-80.7 ms against 79.3-79.7 in the static order, also when only the most expensive
         // 1/64 of the chunks is moved to the front (profiles/r04_cost_order_seeds.txt): a chunk's time is mostly the luck of its 2048
         // samples and of when its wave ran it -- so the seed is part of the key now, and a new seed runs in the static order like a first
-        // launch.  Results do not depend on the dispatch order.  Tuning bit 13 switches it off for this kernel (A/B), SPT_FLAG_ONE_SHOT
-        // for one launch (nothing is recorded either: no clock stores, no ordering kernels, no tables).
+        // launch.  Recording is not free either -- the clock stores and the three ordering kernels behind the frame cost 0.6 ms of an 80 ms
+        // launch (profiles/r04_cost_order_regions.txt) --, so a launch records only when it repeats its predecessor (same view, same seed)
+        // or an order for it exists: a progressive loop never pays, a repeated render runs twice in the static order and is ordered from
+        // its third launch on.  Results do not depend on the dispatch order.  Tuning bit 13 switches it off for this kernel (A/B),
+        // SPT_FLAG_ONE_SHOT for one launch.
         const uint32_t nchunks = (uint32_t)((ntasks + 63) / 64);
         std::vector<unsigned char> key(sizeof(spt_camera) + 10 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
         {
@@ -1066,7 +1070,9 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         // between two frames costs the frames in flight more than it gains; bit 13 means something else to the grid kernel only)
         // (... and not beyond 4 Mi chunks -- 48 MB of tables; a single band of config 4's size is 1 Mi --: the tail the order removes is a
         // fixed few milliseconds, nothing of a launch that long)
-        if (!(c->variant & 0x2000u) && !(flags & SPT_FLAG_ONE_SHOT) && samps >= 16u && nchunks <= (4u << 20)) {
+        const bool have_order = c->order_valid && key == c->order_key;
+        const bool repeats = key == c->last_pool_key;
+        if (!(c->variant & 0x2000u) && !(flags & SPT_FLAG_ONE_SHOT) && samps >= 16u && nchunks <= (4u << 20) && (have_order || repeats)) {
             if (nchunks > c->chunk_cap) {
                 if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
                 c->d_chunk_tables = nullptr; c->chunk_cap = 0; c->order_valid = false;
@@ -1075,7 +1081,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
             }
             uint32_t* const d_order = c->d_chunk_tables;
             uint32_t* const d_clock = c->d_chunk_tables + c->chunk_cap;
-            P.chunk_order = (c->order_valid && key == c->order_key) ? d_order : nullptr;
+            P.chunk_order = (have_order && c->order_valid) ? d_order : nullptr;     // (order_valid: the tables may just have been re-allocated)
             P.chunk_clock = d_clock;
             P.nchunks = nchunks;
             SPT_HIP(c, hipMemsetAsync(d_clock + nchunks, 0, (size_t)nchunks * sizeof(uint32_t), st));
@@ -1090,12 +1096,13 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
             SPT_HIP(c, spt_pool_chunk_order(P.chunk_clock, nchunks, (uint32_t)ntasks, c->d_chunk_tables, c->d_chunk_tables + 3 * c->chunk_cap, st));
             SPT_HIP(c, hipEventRecord(c->ev_order, st));
             c->order_pending = true;
-            c->order_key.swap(key);
+            c->order_key = key;
             c->order_valid = true;
             c->last_nchunks = nchunks;
         } else {
             c->last_nchunks = 0;
         }
+        c->last_pool_key.swap(key);
         c->pending = true;
         c->last_was_pool = true;
         c->last_kernel = 1;
