@@ -192,11 +192,13 @@ def extra_sphere_config(pkg, label, scene, samps, reps=3):
     return res
 
 
-def extra_mesh_config(pkg, samps, reps=3):
-    """The scene the reference ships (smallpt.cpp:31-34: r = 10 diffuse sphere + r = 600 light, 4096 triangles each, scene.h:91) through
-    the exhaustive triangle loop (scene.cpp:95-116), 256x256 (cpuRender's size, :274-275)."""
+def extra_mesh_config(pkg, samps, reps=3, bvh=False):
+    """The scene the reference ships (smallpt.cpp:31-34: r = 10 diffuse sphere + r = 600 light, 4096 triangles each, scene.h:91), 256x256
+    (cpuRender's size, :274-275): through the exhaustive triangle loop (scene.cpp:95-116, what CPUIntersector does) or, bvh=True, through
+    the library's default since round 4, the exhaustive-equivalent hierarchy (the OptixIntersector's role, smallpt.cpp:475-603)."""
     import torch
     r = pkg.Renderer(torch.cuda.current_device())
+    r.set_mesh_accel(pkg.ACCEL_BVH if bvh else pkg.ACCEL_EXHAUSTIVE)
     meshes = [pkg.make_sphere_trimesh((50, 40.8, 81.6), 10.0), pkg.make_sphere_trimesh((50, 681.6 - .27, 81.6), 600.0)]
     mats = [((0, 0, 0), (.75, .25, .25), pkg.DIFF), ((1, 1, 1), (0, 0, 0), pkg.DIFF)]
     r.set_meshes(meshes, mats)
@@ -209,6 +211,18 @@ def extra_mesh_config(pkg, samps, reps=3):
 
     k_ms, st = _timed_launches(r, render, reps)
     ntri = sum(m.triangle_count for m in meshes)
+    if bvh:
+        img = out_t.clone()
+        r.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
+        st_x = render()
+        res = {"workload": f"the reference's shipped scene (2 spheres x 4096 triangles), {w}x{h}, {4 * samps} spp, seed 0, hierarchy (SPT_ACCEL_BVH, the default)",
+               "triangles": ntri, "kernel": "spt::meshkernel<1>", "launches": reps, "kernel_ms": round(k_ms, 3),
+               "value": round(st["samples"] / k_ms / 1e3, 2), "unit": "Msamples/s", "bounces_per_sample": round(st["bounces"] / st["samples"], 4),
+               "rays_per_s": round(st["bounces"] / (k_ms * 1e-3) / 1e9, 3), "rays_unit": "Grays/s (closest-hit queries)",
+               "bit_identical_to_exhaustive": bool(torch.equal(img, out_t)) and st["bounces"] == st_x["bounces"],
+               "roofline": None, "note": "latency-bound pointer chasing (one lane = one ray, dependent 64-byte node loads): no flop or byte roofline is claimed"}
+        r.close()
+        return res
     tests = st["bounces"] * ntri
     ach = tests * 52.0 / (k_ms * 1e-3) / 1e12                   # 52 flop per triIntersect as the reference writes it (scene.cpp:52-70)
     res = {"workload": f"the reference's shipped scene (2 spheres x 4096 triangles), {w}x{h}, {4 * samps} spp, seed 0, exhaustive triangle loop",
@@ -220,7 +234,7 @@ def extra_mesh_config(pkg, samps, reps=3):
     return res
 
 
-EXTRAS = ("config3", "config5", "mesh_4spp", "mesh_256spp")
+EXTRAS = ("config3", "config5", "mesh_4spp", "mesh_256spp", "mesh_4spp_bvh", "mesh_256spp_bvh")
 
 
 def run_extra(pkg, name):
@@ -232,6 +246,10 @@ def run_extra(pkg, name):
         return extra_mesh_config(pkg, 1)
     if name == "mesh_256spp":
         return extra_mesh_config(pkg, 64)
+    if name == "mesh_4spp_bvh":
+        return extra_mesh_config(pkg, 1, bvh=True)
+    if name == "mesh_256spp_bvh":
+        return extra_mesh_config(pkg, 64, bvh=True)
     raise SystemExit(f"unknown extra {name}")
 
 

@@ -128,28 +128,26 @@ typedef struct spt_hit { float dist; uint32_t instId; uint32_t triId; float x[3]
  * un-normalised vertex normal).  spt_set_scene switches back to spheres. */
 int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
 
-/* How the closest hit of a mesh scene is found.
- *   SPT_ACCEL_EXHAUSTIVE (default): every triangle of every instance is tested, as CPUIntersector::intersect does
- *     (smallpt.cpp:443-458 over scene.cpp:95-116).  Bit-identical to the reference's loops on every ray.
- *   SPT_ACCEL_BVH: the role of the OptiX Prime model/query of the reference's GPU intersector (smallpt.cpp:475-603):
- *     a bounding-volume hierarchy built over the triangles when the mode is selected / the meshes are set.  The visited
- *     triangles go through the same triIntersect arithmetic and the same selection (smallest dist > 0, lowest
- *     (instance, triangle) among equal dist), so the result is the exhaustive one whenever the winning triangle's padded
- *     box is crossed by the ray within the current nearest distance -- every hit whose ray passes within rounding
- *     distance of its triangle.  triIntersect has no determinant cut-off (scene.cpp:62): when dot(rd, cross(e1, e2)) is
- *     zero to rounding it reports a "hit" whose distance is rounding noise.  Two cases: (a) a ray lying in the plane of a
- *     regular triangle -- the hierarchy may return the next hit instead; (b) THIN triangles (area <= 2^-10 of the longest edge
- *     squared: the needles makeSphereTriMesh puts at the poles, zero-area triangles), whose float normal is noise for every
- *     ray: these sit in a second hierarchy that is tested along the ray's whole LINE with no distance cut, so every ray whose
- *     line meets a needle's padded box -- rays aimed at the pole vertices included -- gets the exhaustive loop's answer; what
- *     remains is a line that crosses the needle's supporting line away from the needle (seen: 43 units beyond its tip,
- *     u = v = 0.5 exactly), which only the exhaustive loop reports.  tests/test_meshes.py compares both modes on 668 000 rays
- *     (random, through vertices / edge midpoints / centroids, along edges, in-plane with tilts 0 .. 1e-2, axis-parallel,
- *     origins on the surface): 18 differ, 8 of kind (a) and 10 of the remaining kind of (b), each checked to be exactly that;
- *     rendered images (camera rays never meet the conditions exactly) are identical to the exhaustive kernel's and the oracle's.
- * Applies to spt_trace_rays and to spt_render* of a mesh scene; may be changed at any time. */
+/* How the closest hit of a mesh scene is found.  Both modes return the same Hit for EVERY ray (since round 4).
+ *   SPT_ACCEL_BVH (default since round 4): the role of the OptiX Prime model/query of the reference's GPU intersector
+ *     (smallpt.cpp:475-603, the intersector the reference actually runs, :605): structures built over the triangles when the
+ *     meshes are set.  The triangles they reach go through the same triIntersect arithmetic and the same selection (smallest
+ *     dist > 0, lowest (instance, triangle) among equal dist) as the exhaustive loop, and they provably reach every triangle whose
+ *     report beats or ties the answer (csrc/spt_tribvh.h): a bounding-volume hierarchy whose boxes are inflated per ray by the
+ *     error bound of a report; and, because triIntersect has no determinant cut-off (scene.cpp:62) and reports rounding noise
+ *     when dot(rd, cross(e1, e2)) is zero to rounding -- a "hit" no bounding volume contains --, a ball tree over the triangles'
+ *     PLANES that finds the triangles in whose plane the ray lies, and one over the long edges' LINES of thin triangles (the
+ *     needles makeSphereTriMesh puts at the poles: their normal is noise for every ray) that finds the needles whose supporting
+ *     line the ray's line crosses, wherever along it.  Rounds 2 and 3 documented those rays as exceptions (18 of 668 000 test
+ *     rays); tests/test_meshes.py now requires 0 differences on 700 000 random and adversarial rays, the CPU harness
+ *     tests/sanitize/tribvh_main.cpp runs the same walk functions against the exhaustive loop.  A ray that starts hundreds of
+ *     scene sizes away degrades towards the exhaustive loop's cost (the error bound grows with the distance), never in result.
+ *   SPT_ACCEL_EXHAUSTIVE: every triangle of every instance is tested, as CPUIntersector::intersect does (smallpt.cpp:443-458 over
+ *     scene.cpp:95-116): the parity anchor.
+ * Applies to spt_trace_rays and to spt_render* / spt_progressive_* of a mesh scene; may be changed at any time. */
 #define SPT_ACCEL_EXHAUSTIVE 0
 #define SPT_ACCEL_BVH        1
+#define SPT_ACCEL_BVH_FAST   3   /* mesh scenes only: the spatial hierarchy alone (rounds 2-3), see above */
 int  spt_set_mesh_accel(spt_ctx* ctx, int accel);
 /* How the closest hit of a SPHERE table larger than the 24 the material-sorted kernel unrolls is found (smallpt.cpp:54-70 loops
  * over all of them).  Every mode returns the exhaustive loop's hit for every ray -- same intersectAnalytic arithmetic

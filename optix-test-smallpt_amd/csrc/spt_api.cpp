@@ -71,10 +71,12 @@ struct spt_ctx {
     float4* d_sbvh_nodes = nullptr; float4* d_sbvh_geom = nullptr; uint32_t* d_sbvh_index = nullptr; uint32_t* d_sbvh_always = nullptr;
     uint32_t sbvh_nalways = 0, sbvh_depth = 0;
     std::vector<float4> h_tris;      // host copy of the triangle records: the hierarchy is built from it on demand
-    int accel = SPT_ACCEL_EXHAUSTIVE;
+    int accel = SPT_ACCEL_BVH;             // mesh scenes (spt_set_mesh_accel): exhaustive-equivalent for every ray since round 4 (spt_tribvh.h)
     bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
     float4* d_bvh_nodes = nullptr; float4* d_bvh_tris = nullptr; uint32_t* d_bvh_index = nullptr;
-    float4* d_thin_nodes = nullptr; float4* d_thin_tris = nullptr; uint32_t* d_thin_index = nullptr; uint32_t thin_count = 0;   // second hierarchy: thin triangles
+    float4* d_flat_lines = nullptr; uint32_t nthin = 0; bool bvh_flat = false;     // thin triangles as a table (spt_tribvh.h (3))
+    uint32_t* d_cam_planes = nullptr; uint32_t ncam = 0, cam_cap = 0; float cam_key[3] = {0, 0, 0}; bool cam_valid = false;   // spt_bvh.h camera_planes of the last pinhole origin
+    float4* d_bvh_cones = nullptr; float4* d_plane_nodes = nullptr; float4* d_line_nodes = nullptr; bool have_planes = false, have_lines = false;   // spt_tribvh.h
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     uint32_t ntris = 0, ninst = 0;
     float* d_accum = nullptr;      // spt_progressive_*: accumBuffer (smallpt.cpp:881-883) and the current frame, w*h*3 floats each
@@ -218,9 +220,11 @@ void spt_destroy(spt_ctx* c)
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_tris) (void)hipFree(c->d_bvh_tris);
     if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
-    if (c->d_thin_nodes) (void)hipFree(c->d_thin_nodes);
-    if (c->d_thin_tris) (void)hipFree(c->d_thin_tris);
-    if (c->d_thin_index) (void)hipFree(c->d_thin_index);
+    if (c->d_bvh_cones) (void)hipFree(c->d_bvh_cones);
+    if (c->d_cam_planes) (void)hipFree(c->d_cam_planes);
+    if (c->d_flat_lines) (void)hipFree(c->d_flat_lines);
+    if (c->d_plane_nodes) (void)hipFree(c->d_plane_nodes);
+    if (c->d_line_nodes) (void)hipFree(c->d_line_nodes);
     if (c->d_verts) (void)hipFree(c->d_verts);
     if (c->d_inst_first) (void)hipFree(c->d_inst_first);
     if (c->d_mesh_mats) (void)hipFree(c->d_mesh_mats);
@@ -629,7 +633,7 @@ static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, c
     tris.resize(3 * (size_t)ntris);
     c->h_tris.swap(tris);
     c->bvh_ready = false;
-    return c->accel == SPT_ACCEL_BVH ? build_accel(c) : 0;
+    return c->accel != SPT_ACCEL_EXHAUSTIVE ? build_accel(c) : 0;
 }
 
 // Builds and uploads the hierarchy of the current mesh scene (spt_bvh.h); the caller holds the C-boundary try block.
@@ -649,12 +653,12 @@ static int build_accel(spt_ctx* c)
     SPT_HIP(c, upload(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4)));
     SPT_HIP(c, upload(c->d_bvh_tris, bvh.tris.data(), bvh.tris.size() * sizeof(float4)));
     SPT_HIP(c, upload(c->d_bvh_index, bvh.index.data(), bvh.index.size() * sizeof(uint32_t)));
-    c->thin_count = bvh.thin_count;
-    if (bvh.thin_count) {
-        SPT_HIP(c, upload(c->d_thin_nodes, bvh.thin_nodes.data(), bvh.thin_nodes.size() * sizeof(float4)));
-        SPT_HIP(c, upload(c->d_thin_tris, bvh.thin_tris.data(), bvh.thin_tris.size() * sizeof(float4)));
-        SPT_HIP(c, upload(c->d_thin_index, bvh.thin_index.data(), bvh.thin_index.size() * sizeof(uint32_t)));
-    }
+    c->have_planes = !bvh.planes.empty(); c->have_lines = !bvh.lines.empty();
+    if (c->have_planes) SPT_HIP(c, upload(c->d_plane_nodes, bvh.planes.data(), bvh.planes.size() * sizeof(float4)));
+    if (c->have_lines) SPT_HIP(c, upload(c->d_line_nodes, bvh.lines.data(), bvh.lines.size() * sizeof(float4)));
+    c->bvh_flat = bvh.flat && bvh.thin_count; c->nthin = bvh.thin_count; c->cam_valid = false;
+    if (c->bvh_flat) SPT_HIP(c, upload(c->d_flat_lines, bvh.flat_lines.data(), bvh.flat_lines.size() * sizeof(float4)));
+    SPT_HIP(c, upload(c->d_bvh_cones, bvh.cones.data(), bvh.cones.size() * sizeof(float4)));
     c->bvh_nodes = (uint32_t)(bvh.nodes.size() / 4); c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.leaves;
     c->bvh_ready = true;
     return 0;
@@ -663,9 +667,9 @@ static int build_accel(spt_ctx* c)
 int spt_set_mesh_accel(spt_ctx* c, int accel)
 {
     if (!c) return 1;
-    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH) return c->fail("spt_set_mesh_accel: unknown mode %d", accel);
+    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH && accel != SPT_ACCEL_BVH_FAST) return c->fail("spt_set_mesh_accel: unknown mode %d", accel);
     c->accel = accel;
-    if (accel != SPT_ACCEL_BVH || !c->mesh_scene || c->bvh_ready) return 0;
+    if (accel == SPT_ACCEL_EXHAUSTIVE || !c->mesh_scene || c->bvh_ready) return 0;
     try {
         return build_accel(c);
     } catch (const std::exception& e) {
@@ -697,7 +701,7 @@ int spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, cha
         spt::build_bvh(recs.data(), ntris, bvh);
         std::string reason;
         const bool ok = spt::validate_bvh(recs.data(), ntris, bvh, reason);
-        if (out4) { out4[0] = (uint32_t)(bvh.nodes.size() / 4); out4[1] = bvh.leaves; out4[2] = bvh.depth; out4[3] = ntris - bvh.thin_count; }
+        if (out4) { out4[0] = (uint32_t)(bvh.nodes.size() / 4); out4[1] = bvh.leaves; out4[2] = bvh.depth; out4[3] = bvh.regular_count; }
         if (why && why_len) std::snprintf(why, why_len, "%s", reason.c_str());
         return ok ? 0 : 2;
     } catch (const std::exception& e) {
@@ -711,9 +715,14 @@ static spt::MParams mesh_params(const spt_ctx* c)
     spt::MParams M{};
     M.tris = c->d_tris; M.tri_index = c->d_tri_index; M.verts = c->d_verts; M.inst_first_tri = c->d_inst_first; M.mats = c->d_mesh_mats;
     M.ntris = c->ntris; M.ninst = c->ninst;
-    if (c->accel == SPT_ACCEL_BVH && c->bvh_ready) {
+    if (c->accel != SPT_ACCEL_EXHAUSTIVE && c->bvh_ready) {
         M.bvh_nodes = c->d_bvh_nodes; M.bvh_tris = c->d_bvh_tris; M.bvh_index = c->d_bvh_index;
-        if (c->thin_count) { M.thin_nodes = c->d_thin_nodes; M.thin_tris = c->d_thin_tris; M.thin_index = c->d_thin_index; }
+        if (c->accel == SPT_ACCEL_BVH) {                           // (SPT_ACCEL_BVH_FAST: the spatial tree alone, no cones)
+            M.bvh_cones = c->d_bvh_cones;
+            if (c->have_planes) M.plane_nodes = c->d_plane_nodes;
+            if (c->have_lines) M.line_nodes = c->d_line_nodes;
+            if (c->bvh_flat) { M.flat_lines = c->d_flat_lines; M.nthin = c->nthin; }
+        }
     }
     return M;
 }
@@ -970,7 +979,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
     if (c->mesh_scene || sphere_bvh) {
         // (a short launch -- the viewer's frames -- takes three workgroups per CU instead of four: 661 -> 672 frames/s on the shipped scene
         // through the hierarchy at 1280x720 x 4 spp, 949 -> 1033 with two frames in flight, which then share the CUs; tools/ab_mesh_viewer_blocks.py)
-        const bool through_hierarchy = sphere_bvh || (c->mesh_scene && c->accel == SPT_ACCEL_BVH && c->bvh_ready);   // (the exhaustive tile loop keeps four)
+        const bool through_hierarchy = sphere_bvh || (c->mesh_scene && c->accel != SPT_ACCEL_EXHAUSTIVE && c->bvh_ready);   // (the exhaustive tile loop keeps four)
         const uint32_t mesh_per_cu = c->blocks_per_cu ? c->blocks_per_cu : (through_hierarchy && npix * 4ull * samps < (4ull << 20) ? 3u : 4u);
         uint64_t blocks = (uint64_t)c->cu_count * mesh_per_cu;
         const uint64_t needed = (ntasks + 255) / 256;
@@ -991,6 +1000,27 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         } else {
             P.n = 0; P.n_pad = 1; P.geom = nullptr; P.mat = nullptr;
             M = mesh_params(c);
+            if (M.plane_nodes && cam->push == 0.0f) {
+                // a pinhole camera: every ray of depth 0 starts at cam->origin, and a ray can only be reported by a regular triangle through
+                // a determinant that is zero to rounding if its ORIGIN lies in that triangle's plane (spt_tribvh.h (2), condition (B)):
+                // those triangles are listed once per camera position (none, as a rule) and the camera rays skip the plane tree
+                if (!c->cam_valid || std::memcmp(c->cam_key, cam->origin, sizeof c->cam_key) != 0) {
+                    std::vector<uint32_t> list;
+                    spt::camera_planes(c->h_tris.data(), c->ntris, cam->origin, list);
+                    if (list.size() > c->cam_cap) {
+                        if (c->d_cam_planes) (void)hipFree(c->d_cam_planes);
+                        c->d_cam_planes = nullptr; c->cam_cap = 0;
+                        SPT_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_cam_planes), list.size() * sizeof(uint32_t)));
+                        c->cam_cap = (uint32_t)list.size();
+                    }
+                    if (!list.empty()) SPT_HIP(c, hipMemcpyAsync(c->d_cam_planes, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    if (!list.empty()) SPT_HIP(c, hipStreamSynchronize(st));           // (the list is a local)
+                    c->ncam = (uint32_t)list.size();
+                    std::memcpy(c->cam_key, cam->origin, sizeof c->cam_key);
+                    c->cam_valid = true;
+                }
+                M.cam_planes = c->d_cam_planes; M.ncam = c->ncam; M.cam_cull = 1u;
+            }
         }
         SPT_HIP(c, hipMemsetAsync(c->d_queue, 0, 256, st));
         SPT_HIP(c, hipEventRecord(c->ev_start, st));

@@ -69,6 +69,46 @@ struct Builder {
     std::vector<float> cen;          // 3 per primitive
     std::vector<uint32_t> order;     // permutation being partitioned
     Bvh* out;
+    // triangle hierarchies only (spt_tribvh.h (1)): unit normal, g and longest edge per primitive -> a cone per child in out->cones
+    std::vector<double> nrm, gq, el;
+
+    struct Cone { float a[3]; float kappa, iq, ee; };
+    Cone range_cone(uint32_t lo, uint32_t hi) const
+    {
+        Cone c{{1.f, 0.f, 0.f}, 2.0f, 1.0f, 0.0f};
+        if (lo == hi) return c;
+        const double* ref = &nrm[3 * (size_t)order[lo]];
+        double mean[3] = {0, 0, 0}, gmax = 1.0, emax = 0.0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const double* q = &nrm[3 * (size_t)order[i]];
+            const double sgn = q[0] * ref[0] + q[1] * ref[1] + q[2] * ref[2] < 0.0 ? -1.0 : 1.0;      // either orientation of a normal
+            for (int k = 0; k < 3; ++k) mean[k] += sgn * q[k];
+            gmax = std::max(gmax, gq[order[i]]); emax = std::max(emax, el[order[i]]);
+        }
+        const double len = std::sqrt(mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+        if (len > 1e-6 * (hi - lo)) for (int k = 0; k < 3; ++k) c.a[k] = (float)(mean[k] / len);
+        const double al = std::sqrt((double)c.a[0] * c.a[0] + (double)c.a[1] * c.a[1] + (double)c.a[2] * c.a[2]);   // the stored axis is a unit vector up to 1e-7
+        double kap = 0.0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const double* q = &nrm[3 * (size_t)order[i]];
+            double dm = 0.0, dp = 0.0;
+            for (int k = 0; k < 3; ++k) { dm += (q[k] - c.a[k]) * (q[k] - c.a[k]); dp += (q[k] + c.a[k]) * (q[k] + c.a[k]); }
+            kap = std::max(kap, std::sqrt(std::min(dm, dp)));
+        }
+        c.kappa = round_up(kap + std::fabs(al - 1.0) + 1e-6);
+        c.iq = round_down(1.0 / gmax);
+        c.ee = round_up(1.016 * emax);
+        return c;
+    }
+    void store_cones(uint32_t node, const Cone& l, const Cone& r)
+    {
+        if (nrm.empty()) return;
+        if (out->cones.size() < 3 * (size_t)(node + 1)) out->cones.resize(3 * (size_t)(node + 1));
+        float4* cn = &out->cones[3 * (size_t)node];
+        cn[0] = make_float4(l.a[0], l.a[1], l.a[2], l.kappa);
+        cn[1] = make_float4(r.a[0], r.a[1], r.a[2], r.kappa);
+        cn[2] = make_float4(l.iq, l.ee, r.iq, r.ee);
+    }
 
     int32_t leaf_ref(uint32_t lo, uint32_t hi)
     {
@@ -104,6 +144,7 @@ struct Builder {
             std::memcpy(&refs.x, &lr, 4); std::memcpy(&refs.y, &rr, 4);
             out->nodes[3] = refs;
             out->depth = 1;
+            if (!nrm.empty()) store_cones(0, range_cone(0, n), range_cone(0, 0));
         } else {
             const int32_t root = build(0, n, 0);
             if (root != 0) throw std::runtime_error("hierarchy: internal error (root is not node 0)");
@@ -182,6 +223,7 @@ struct Builder {
         out->nodes.resize(out->nodes.size() + 4);
         const uint32_t m = split(lo, hi, kBvhMaxDepth - (depth + 1));
         const Box l = range_box(lo, m), r = range_box(m, hi);
+        if (!nrm.empty()) store_cones(node, range_cone(lo, m), range_cone(m, hi));
         const int32_t lr = build(lo, m, depth + 1), rr = build(m, hi, depth + 1);
         float4* nd = &out->nodes[4 * (size_t)node];
         nd[0] = make_float4(l.mn[0], l.mn[1], l.mn[2], l.mx[0]);
@@ -196,40 +238,300 @@ struct Builder {
 
 }  // namespace
 
-// A needle: the record's normal cross(e1, e2) is tiny against the longest edge squared (zero-area triangles included)
-static bool thin_triangle(const float4* r)
+// ---- triangle classes and the two ball trees of spt_tribvh.h ---------------------------------------------------------------
+namespace {
+
+enum TriClass { kTriDead = 0, kTriRegular = 1, kTriThin = 2 };
+
+struct TriGeom {
+    double v0[3], e1[3], e2[3], n[3];     // n = e1 x e2 in double (exact products of floats, one rounding of 2^-53 in the difference)
+    double l1, l2, nn, g;                 // |e1|, |e2|, |n|, g = |e1||e2| / |n| (inf for n = 0)
+    TriClass cls;
+};
+
+inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void cross3(const double* a, const double* b, double* c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; }
+
+TriGeom tri_geom(const float4* r)
 {
-    const double e1[3] = {r[1].x, r[1].y, r[1].z}, e2[3] = {r[2].x, r[2].y, r[2].z}, n[3] = {r[0].w, r[1].w, r[2].w};
-    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
-    auto sq = [](const double* v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; };
-    const double longest2 = std::max({sq(e1), sq(e2), sq(e3)});
-    return !(sq(n) > kBvhThinRatio * kBvhThinRatio * longest2 * longest2);
+    TriGeom t;
+    t.v0[0] = r[0].x; t.v0[1] = r[0].y; t.v0[2] = r[0].z;
+    t.e1[0] = r[1].x; t.e1[1] = r[1].y; t.e1[2] = r[1].z;
+    t.e2[0] = r[2].x; t.e2[1] = r[2].y; t.e2[2] = r[2].z;
+    cross3(t.e1, t.e2, t.n);
+    t.l1 = std::sqrt(dot3(t.e1, t.e1)); t.l2 = std::sqrt(dot3(t.e2, t.e2)); t.nn = std::sqrt(dot3(t.n, t.n));
+    const double E = t.l1 * t.l2;
+    t.g = t.nn > 0.0 ? E / t.nn : std::numeric_limits<double>::infinity();
+    t.cls = !(E > 0.0) ? kTriDead : (t.g <= kTriThinG ? kTriRegular : kTriThin);
+    return t;
 }
 
-void build_bvh(const float4* recs, uint32_t ntris, Bvh& out)
+// One triangle as the cone trees see it: a unit direction (plane normal or long-edge direction; either sign), the point v0, its
+// tolerance (tau of spt_tribvh.h (2) or a of (3)) and its longest edge.
+struct ConeItem { double d[3], v0[3], tol, edge; uint32_t gid; };
+
+ConeItem cone_item(const TriGeom& t, uint32_t gid)
+{
+    ConeItem c{};
+    c.gid = gid;
+    for (int a = 0; a < 3; ++a) c.v0[a] = t.v0[a];
+    c.edge = std::max(t.l1, t.l2);
+    if (t.cls == kTriRegular) {
+        for (int a = 0; a < 3; ++a) c.d[a] = t.n[a] / t.nn;
+        c.tol = kTriBand * t.g;
+    } else {
+        const bool first_longer = t.l1 >= t.l2;
+        const double* eL = first_longer ? t.e1 : t.e2;
+        const double lL = first_longer ? t.l1 : t.l2, lS = first_longer ? t.l2 : t.l1;
+        for (int a = 0; a < 3; ++a) c.d[a] = eL[a] / lL;
+        c.tol = lS * ((std::isfinite(t.g) ? 1.0 / t.g : 0.0) + 7.2 * 0x1p-24);
+    }
+    return c;
+}
+
+struct ConeChild { float a[3], kappa, p[3], s1, s2, s3; };   // planes: s1 = sigma, s2 = tau, s3 = te;  lines: s1 = lam
+
+// solves the symmetric 3 x 3 system A x = b (A positive definite by construction: a regularisation sits on its diagonal)
+inline bool solve3(const double A[3][3], const double b[3], double x[3])
+{
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double inv[3][3] = {{c00, A[0][2] * A[2][1] - A[0][1] * A[2][2], A[0][1] * A[1][2] - A[0][2] * A[1][1]},
+                              {c01, A[0][0] * A[2][2] - A[0][2] * A[2][0], A[0][2] * A[1][0] - A[0][0] * A[1][2]},
+                              {c02, A[0][1] * A[2][0] - A[0][0] * A[2][1], A[0][0] * A[1][1] - A[0][1] * A[1][0]}};
+    for (int i = 0; i < 3; ++i) x[i] = (inv[i][0] * b[0] + inv[i][1] * b[1] + inv[i][2] * b[2]) / det;
+    return std::isfinite(x[0]) && std::isfinite(x[1]) && std::isfinite(x[2]);
+}
+
+// Tree over ConeItems, clustered by direction and position; PLANES = true: spt_tribvh.h (2), else (3).
+struct ConeBuilder {
+    bool planes = true;
+    std::vector<ConeItem> items;
+    std::vector<uint32_t> order;
+    std::vector<float4>* nodes = nullptr;
+    double dir_scale = 1.0;           // one unit of direction difference counts as this much distance when splitting (the scene's size)
+    uint32_t depth = 0;
+    uint32_t node_f4() const { return planes ? 6u : 5u; }
+
+    ConeChild summary(uint32_t lo, uint32_t hi)
+    {
+        ConeChild c{};
+        c.a[0] = 1.f; c.kappa = -1e30f;                                  // empty child: never entered
+        if (lo == hi) return c;
+        const uint32_t n = hi - lo;
+        const double* ref = items[order[lo]].d;
+        double mean[3] = {0, 0, 0}, cen[3] = {0, 0, 0};
+        for (uint32_t i = lo; i < hi; ++i) {
+            ConeItem& it = items[order[i]];
+            if (dot3(it.d, ref) < 0.0) for (int k = 0; k < 3; ++k) it.d[k] = -it.d[k];      // same plane / line, the orientation next to the first one's
+            for (int k = 0; k < 3; ++k) { mean[k] += it.d[k]; cen[k] += it.v0[k] / n; }
+        }
+        const double len = std::sqrt(dot3(mean, mean));
+        if (len > 1e-9 * n) for (int k = 0; k < 3; ++k) c.a[k] = (float)(mean[k] / len);
+        // reference point: where the cluster's planes (lines) come closest to meeting, pulled to the centroid of the v0 where they do not say
+        double p[3] = {cen[0], cen[1], cen[2]};
+        if (n > 1) {
+            double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, b[3] = {0, 0, 0};
+            for (uint32_t i = lo; i < hi; ++i) {
+                const ConeItem& it = items[order[i]];
+                const double rel[3] = {it.v0[0] - cen[0], it.v0[1] - cen[1], it.v0[2] - cen[2]};
+                const double dr = dot3(it.d, rel);
+                for (int r = 0; r < 3; ++r) {
+                    for (int q = 0; q < 3; ++q) A[r][q] += planes ? it.d[r] * it.d[q] : ((r == q ? 1.0 : 0.0) - it.d[r] * it.d[q]);
+                    b[r] += planes ? it.d[r] * dr : rel[r] - it.d[r] * dr;
+                }
+            }
+            const double reg = 1e-4 * n;
+            for (int r = 0; r < 3; ++r) A[r][r] += reg;
+            double x[3];
+            if (solve3(A, b, x)) for (int k = 0; k < 3; ++k) p[k] = cen[k] + x[k];
+        }
+        for (int k = 0; k < 3; ++k) c.p[k] = (float)p[k];
+        const double al = std::sqrt((double)c.a[0] * c.a[0] + (double)c.a[1] * c.a[1] + (double)c.a[2] * c.a[2]);
+        double kap = 0.0, s1 = 0.0, tmax = 0.0, rho = 0.0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const ConeItem& it = items[order[i]];
+            double dm = 0.0, dp = 0.0;
+            for (int k = 0; k < 3; ++k) { dm += (it.d[k] - c.a[k]) * (it.d[k] - c.a[k]); dp += (it.d[k] + c.a[k]) * (it.d[k] + c.a[k]); }
+            kap = std::max(kap, std::sqrt(std::min(dm, dp)));
+            const double rel[3] = {it.v0[0] - c.p[0], it.v0[1] - c.p[1], it.v0[2] - c.p[2]};
+            const double r = std::sqrt(dot3(rel, rel));
+            rho = std::max(rho, r);
+            if (planes) {
+                s1 = std::max(s1, std::fabs(dot3(it.d, rel)));
+                tmax = std::max(tmax, it.tol);
+            } else {
+                double cr[3];
+                cross3(it.d, rel, cr);
+                s1 = std::max(s1, std::sqrt(dot3(cr, cr)) + it.tol + 8.1 * 0x1p-24 * r);
+            }
+        }
+        c.kappa = round_up(kap + std::fabs(al - 1.0) + 1e-7);
+        c.s1 = round_up(s1 * (1.0 + 1e-9) + 1e-30);
+        if (planes) {
+            double te = 0.0;
+            for (uint32_t i = lo; i < hi; ++i) te = std::max(te, items[order[i]].tol * (rho + 2.0 * items[order[i]].edge) * 1.001);
+            c.s2 = round_up(tmax);
+            c.s3 = round_up(te);
+        }
+        return c;
+    }
+
+    void store(uint32_t node, const ConeChild& l, const ConeChild& r, int32_t lr, int32_t rr)
+    {
+        float4* nd = &(*nodes)[(size_t)node_f4() * node];
+        float4 refs = make_float4(0.f, 0.f, 0.f, 0.f);
+        std::memcpy(&refs.x, &lr, 4); std::memcpy(&refs.y, &rr, 4);
+        nd[0] = make_float4(l.a[0], l.a[1], l.a[2], l.kappa);
+        nd[1] = make_float4(l.p[0], l.p[1], l.p[2], l.s1);
+        nd[2] = make_float4(r.a[0], r.a[1], r.a[2], r.kappa);
+        nd[3] = make_float4(r.p[0], r.p[1], r.p[2], r.s1);
+        if (planes) { nd[4] = make_float4(l.s2, l.s3, r.s2, r.s3); nd[5] = refs; }
+        else nd[4] = refs;
+    }
+
+    // subtree over order[lo, hi), hi - lo >= 2; its reference sits at depth `d`
+    int32_t build(uint32_t lo, uint32_t hi, uint32_t d)
+    {
+        if (d >= kBvhMaxDepth) throw std::runtime_error("spt_set_mesh_accel: cone tree depth bound violated");
+        const uint32_t node = (uint32_t)(nodes->size() / node_f4());
+        nodes->resize(nodes->size() + node_f4());
+        (void)summary(lo, hi);                                            // aligns the orientations of the whole range to its first item
+        double mn[6], mx[6];
+        for (int k = 0; k < 6; ++k) { mn[k] = std::numeric_limits<double>::infinity(); mx[k] = -mn[k]; }
+        auto coord = [&](uint32_t g, int k) { return k < 3 ? items[g].d[k] : items[g].v0[k - 3]; };
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int k = 0; k < 6; ++k) { const double v = coord(order[i], k); mn[k] = std::min(mn[k], v); mx[k] = std::max(mx[k], v); }
+        // two candidate median splits -- along the widest direction axis and along the widest position axis --; the one whose children
+        // are the tighter pair wins: kappa (times the scene's size: what a unit of direction costs in (B) / the line test) + sigma / lam,
+        // weighted by the children's sizes.  Splitting by direction alone would keep the same-facing patches of different objects
+        // together, whose planes (lines) pass nowhere near each other.
+        int ad = 0, ap = 3;
+        for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ad] - mn[ad]) ad = k;
+        for (int k = 4; k < 6; ++k) if (mx[k] - mn[k] > mx[ap] - mn[ap]) ap = k;
+        const uint32_t m = lo + (hi - lo + 1) / 2;
+        auto split_on = [&](int a) {
+            std::nth_element(order.begin() + lo, order.begin() + m, order.begin() + hi, [&](uint32_t x, uint32_t y) {
+                const double cx = coord(x, a), cy = coord(y, a);
+                return cx < cy || (cx == cy && x < y);
+            });
+        };
+        auto cost_of = [&]() {
+            const ConeChild l = summary(lo, m), r = summary(m, hi);
+            return (double)(m - lo) * ((double)l.kappa * dir_scale + l.s1) + (double)(hi - m) * ((double)r.kappa * dir_scale + r.s1);
+        };
+        int a = ad;
+        if (mx[ap] - mn[ap] > 0.0 && mx[ad] - mn[ad] > 0.0) {
+            split_on(ap);
+            const double cp = cost_of();
+            split_on(ad);
+            const double cd = cost_of();
+            if (cp < cd) { a = ap; split_on(ap); }
+        } else {
+            if (!(mx[ad] - mn[ad] > 0.0)) a = ap;
+            split_on(a);
+        }
+        (void)summary(lo, hi);                                            // the candidates' summaries re-oriented the halves: align the range again
+        depth = std::max(depth, d + 1);
+        const int32_t lr = m - lo == 1 ? ~(int32_t)items[order[lo]].gid : build(lo, m, d + 1);
+        const int32_t rr = hi - m == 1 ? ~(int32_t)items[order[m]].gid : build(m, hi, d + 1);
+        store(node, summary(lo, m), summary(m, hi), lr, rr);
+        return (int32_t)node;
+    }
+
+    void run()
+    {
+        const uint32_t n = (uint32_t)items.size();
+        nodes->clear();
+        if (n == 0) return;
+        if (n >= 0x7FFFFFFFu) throw std::runtime_error("spt_set_mesh_accel: too many triangles for the leaf encoding");
+        order.resize(n);
+        std::iota(order.begin(), order.end(), 0u);
+        if (n == 1) {
+            nodes->resize(node_f4());
+            depth = 1;
+            store(0, summary(0, 1), summary(0, 0), ~(int32_t)items[0].gid, ~(int32_t)items[0].gid);
+            return;
+        }
+        if (build(0, n, 0) != 0) throw std::runtime_error("cone tree: internal error (root is not node 0)");
+    }
+};
+
+// the scene's size (largest extent of the vertices' bounding box), for the direction / position balance of the cone trees' splits
+double scene_size(const float4* recs, uint32_t ntris)
+{
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t g = 0; g < ntris; ++g) {
+        const float4* r = recs + 3 * (size_t)g;
+        const double v[3][3] = {{r[0].x, r[0].y, r[0].z}, {(double)r[0].x + r[1].x, (double)r[0].y + r[1].y, (double)r[0].z + r[1].z},
+                                {(double)r[0].x + r[2].x, (double)r[0].y + r[2].y, (double)r[0].z + r[2].z}};
+        for (auto& p : v) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    const double s = ntris ? std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}) : 1.0;
+    return std::isfinite(s) && s > 0.0 ? s : 1.0;
+}
+
+}  // namespace
+
+void build_bvh(const float4* recs, uint32_t ntris, Bvh& out, int form)
 {
     out = Bvh{};
-    // two hierarchies of the same layout: the regular triangles (ray segment, distance cut) and the thin ones (whole line, no cut)
-    Bvh thin;
-    Builder b, t;
+    Builder b;
     b.recs = recs; b.rec_f4 = 3; b.out = &out;
-    t.recs = recs; t.rec_f4 = 3; t.out = &thin;
+    std::vector<Box> boxes(ntris);
+    for (uint32_t g = 0; g < ntris; ++g) boxes[g] = padded_box(recs + 3 * (size_t)g);      // throws on non-finite vertices
+    ConeBuilder planes, lines;
+    planes.planes = true; planes.nodes = &out.planes;
+    lines.planes = false; lines.nodes = &out.lines;
+    planes.dir_scale = lines.dir_scale = scene_size(recs, ntris);
     for (uint32_t g = 0; g < ntris; ++g) {
-        const Box bx = padded_box(recs + 3 * (size_t)g);
-        Builder& dst = thin_triangle(recs + 3 * (size_t)g) ? t : b;
-        dst.ids.push_back(g);
-        dst.box.push_back(bx);
-        for (int a = 0; a < 3; ++a) dst.cen.push_back(0.5f * bx.mn[a] + 0.5f * bx.mx[a]);
+        const TriGeom t = tri_geom(recs + 3 * (size_t)g);
+        if (t.cls == kTriDead) { ++out.dead_count; continue; }
+        (t.cls == kTriRegular ? planes : lines).items.push_back(cone_item(t, g));
+        if (t.cls != kTriRegular) continue;
+        b.ids.push_back(g);
+        for (int a = 0; a < 3; ++a) b.nrm.push_back(t.n[a] / t.nn);
+        b.gq.push_back(t.g);
+        b.el.push_back(std::max(t.l1, t.l2));
+        b.box.push_back(boxes[g]);
+        for (int a = 0; a < 3; ++a) b.cen.push_back(0.5f * boxes[g].mn[a] + 0.5f * boxes[g].mx[a]);
     }
-    const uint32_t nthin = (uint32_t)t.ids.size();
+    out.regular_count = (uint32_t)planes.items.size();
+    out.thin_count = (uint32_t)lines.items.size();
+    if (b.ids.empty()) { b.nrm.assign(3, 0.0); b.nrm[0] = 1.0; }             // an empty tree still carries (never read) cones
     b.run();
-    if (nthin) {
-        t.run();
-        out.thin_nodes.swap(thin.nodes); out.thin_tris.swap(thin.tris); out.thin_index.swap(thin.index);
-        out.thin_count = nthin;
-        out.depth = std::max(out.depth, thin.depth);
+    if (out.cones.size() < 3 * (out.nodes.size() / 4)) out.cones.resize(3 * (out.nodes.size() / 4), make_float4(1.f, 0.f, 0.f, 2.f));
+    planes.run();
+    out.flat = form == 1 || (form == 0 && out.thin_count <= kTriFlatLines);     // the thin triangles as a table or as a tree (spt_tribvh.h (3))
+    if (out.flat) {
+        for (const ConeItem& it : lines.items) {
+            float4 v = make_float4((float)it.v0[0], (float)it.v0[1], (float)it.v0[2], 0.f);
+            std::memcpy(&v.w, &it.gid, 4);
+            out.flat_lines.push_back(make_float4((float)it.d[0], (float)it.d[1], (float)it.d[2], round_up(it.tol * (1.0 + 1e-6))));
+            out.flat_lines.push_back(v);
+        }
+    } else {
+        lines.run();
+    }
+    out.ball_depth = std::max(planes.depth, lines.depth);
+}
+
+// The regular triangles in whose plane the point `o` lies to within condition (B) of spt_tribvh.h (2): the only ones a ray that STARTS
+// at o can be reported by through a determinant that is zero to rounding.  For the rays of a pinhole camera -- one origin for a whole
+// frame -- this short list (empty, as a rule) replaces the walk of the plane tree.
+void camera_planes(const float4* recs, uint32_t ntris, const float o[3], std::vector<uint32_t>& out)
+{
+    out.clear();
+    for (uint32_t g = 0; g < ntris; ++g) {
+        const TriGeom t = tri_geom(recs + 3 * (size_t)g);
+        if (t.cls != kTriRegular) continue;
+        const double r[3] = {(double)o[0] - t.v0[0], (double)o[1] - t.v0[1], (double)o[2] - t.v0[2]};
+        const double R = std::sqrt(dot3(r, r)), e = std::max(t.l1, t.l2), tau = kTriBand * t.g;
+        if (!(std::fabs(dot3(t.n, r)) / t.nn > tau * (R + 2.0 * e) * (1.0 + 0x1p-9) + 1e-30)) out.push_back(g);      // (NaN origins list everything)
     }
 }
+
 
 // Box of a sphere, rounded outward, NOT padded: the traversal inflates node boxes per ray (spt_mesh.hip, closest_sphere_bvh)
 static Box sphere_box(const float4 g, float radius)
@@ -326,21 +628,146 @@ static bool validate_walk(const float4* recs, uint32_t rec_f4, uint32_t ntris, c
     return true;
 }
 
+// A cone tree against the triangles it was built over: every triangle of the class in exactly one leaf and, for every ancestor child,
+// inside its cone (either orientation) and within its sigma / tau / te (planes) or lam (lines); depth bound respected.
+static bool validate_cone_tree(const std::vector<float4>& nodes, bool planes, const std::vector<ConeItem>& item_of, const std::vector<uint32_t>& expect, std::string& why)
+{
+    const uint32_t f4 = planes ? 6u : 5u, ntris = (uint32_t)expect.size();
+    std::vector<uint32_t> seen(ntris, 0u);
+    uint32_t want = 0;
+    for (uint32_t e : expect) want += e;
+    if (want == 0) { if (!nodes.empty()) { why = "nodes without triangles"; return false; } return true; }
+    if (nodes.empty() || nodes.size() % f4) { why = "node array size"; return false; }
+    struct Item { int32_t ref; uint32_t depth; int parent; };
+    struct Link { ConeChild c; int parent; };
+    std::vector<Link> chain;
+    std::vector<Item> stack;
+    stack.push_back({0, 0u, -1});
+    size_t visited = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (it.ref < 0) {
+            const uint32_t g = (uint32_t)~it.ref;
+            if (g >= ntris || !expect[g]) { why = "leaf names a triangle of another class"; return false; }
+            if (it.depth > kBvhMaxDepth) { why = "leaf deeper than the bound"; return false; }
+            ++seen[g];
+            const ConeItem& t = item_of[g];
+            for (int l = it.parent; l >= 0; l = chain[l].parent) {
+                const ConeChild& c = chain[l].c;
+                const double al = std::sqrt((double)c.a[0] * c.a[0] + (double)c.a[1] * c.a[1] + (double)c.a[2] * c.a[2]);
+                double dm = 0.0, dp = 0.0;
+                for (int k = 0; k < 3; ++k) { dm += (t.d[k] - c.a[k] / al) * (t.d[k] - c.a[k] / al); dp += (t.d[k] + c.a[k] / al) * (t.d[k] + c.a[k] / al); }
+                if (!(std::sqrt(std::min(dm, dp)) <= (double)c.kappa)) { why = "triangle " + std::to_string(g) + " outside an ancestor's cone"; return false; }
+                const double rel[3] = {t.v0[0] - c.p[0], t.v0[1] - c.p[1], t.v0[2] - c.p[2]};
+                const double r = std::sqrt(dot3(rel, rel));
+                if (planes) {
+                    if (!(std::fabs(dot3(t.d, rel)) <= (double)c.s1 && t.tol <= (double)c.s2 && t.tol * (r + 2.0 * t.edge) <= (double)c.s3)) {
+                        why = "triangle " + std::to_string(g) + ": sigma / tau / te of an ancestor"; return false;
+                    }
+                } else {
+                    double cr[3];
+                    cross3(t.d, rel, cr);
+                    if (!(std::sqrt(dot3(cr, cr)) + t.tol + 8.1 * 0x1p-24 * r <= (double)c.s1)) { why = "triangle " + std::to_string(g) + ": lam of an ancestor"; return false; }
+                }
+            }
+            continue;
+        }
+        if ((size_t)it.ref * f4 + f4 > nodes.size()) { why = "node index"; return false; }
+        if (++visited > nodes.size() / f4) { why = "cycle"; return false; }
+        if (it.depth + 1 > kBvhMaxDepth) { why = "node deeper than the bound"; return false; }
+        const float4* nd = &nodes[(size_t)f4 * it.ref];
+        int32_t lr, rr;
+        std::memcpy(&lr, &nd[f4 - 1].x, 4); std::memcpy(&rr, &nd[f4 - 1].y, 4);
+        for (int side = 0; side < 2; ++side) {
+            const float4 ax = nd[side ? 2 : 0], pt = nd[side ? 3 : 1];
+            ConeChild c{};
+            c.a[0] = ax.x; c.a[1] = ax.y; c.a[2] = ax.z; c.kappa = ax.w; c.p[0] = pt.x; c.p[1] = pt.y; c.p[2] = pt.z; c.s1 = pt.w;
+            if (planes) { c.s2 = side ? nd[4].z : nd[4].x; c.s3 = side ? nd[4].w : nd[4].y; }
+            if (c.kappa < 0.f) continue;                                      // empty child (a tree over one triangle)
+            chain.push_back({c, it.parent});
+            stack.push_back({side ? rr : lr, it.depth + 1, (int)chain.size() - 1});
+        }
+    }
+    for (uint32_t g = 0; g < ntris; ++g)
+        if (seen[g] != expect[g]) { why = "triangle " + std::to_string(g) + " referenced " + std::to_string(seen[g]) + " times"; return false; }
+    return true;
+}
+
+// The cones of the spatial tree (spt_tribvh.h (1)): every regular triangle's normal within kappa of each ancestor child's axis (either
+// orientation), its 1 / g >= the stored one, its longest edge within the stored one.
+static bool validate_cones(const Bvh& bvh, const std::vector<TriGeom>& geo, std::string& why)
+{
+    if (bvh.cones.size() != 3 * (bvh.nodes.size() / 4)) { why = "cone array size"; return false; }
+    struct Link { float4 axis; float iq, ee; int parent; };
+    struct Item { int32_t ref; int parent; };
+    std::vector<Link> chain;
+    std::vector<Item> stack;
+    stack.push_back({0, -1});
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (it.ref < 0) {
+            const uint32_t code = (uint32_t)~it.ref, first = code >> 3, cnt = code & 7u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const TriGeom& t = geo[bvh.index[first + k]];
+                const double nh[3] = {t.n[0] / t.nn, t.n[1] / t.nn, t.n[2] / t.nn};
+                for (int l = it.parent; l >= 0; l = chain[l].parent) {
+                    const Link& c = chain[l];
+                    const double ax[3] = {c.axis.x, c.axis.y, c.axis.z};
+                    const double al = std::sqrt(dot3(ax, ax));
+                    double dm = 0.0, dp = 0.0;
+                    for (int a = 0; a < 3; ++a) { dm += (nh[a] - ax[a] / al) * (nh[a] - ax[a] / al); dp += (nh[a] + ax[a] / al) * (nh[a] + ax[a] / al); }
+                    if (!(std::sqrt(std::min(dm, dp)) <= (double)c.axis.w)) { why = "a normal outside an ancestor's cone"; return false; }
+                    if (!(1.0 / t.g >= (double)c.iq && 1.016 * std::max(t.l1, t.l2) <= (double)c.ee)) { why = "g / edge bound of an ancestor's cone"; return false; }
+                }
+            }
+            continue;
+        }
+        const float4* nd = &bvh.nodes[4 * (size_t)it.ref];
+        const float4* cn = &bvh.cones[3 * (size_t)it.ref];
+        int32_t lr, rr;
+        std::memcpy(&lr, &nd[3].x, 4); std::memcpy(&rr, &nd[3].y, 4);
+        chain.push_back({cn[0], cn[2].x, cn[2].y, it.parent});
+        stack.push_back({lr, (int)chain.size() - 1});
+        chain.push_back({cn[1], cn[2].z, cn[2].w, it.parent});
+        stack.push_back({rr, (int)chain.size() - 1});
+    }
+    return true;
+}
+
 bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why)
 {
     std::vector<Box> pb(ntris);
-    std::vector<uint32_t> regular(ntris, 1u), thin(ntris, 0u);
-    uint32_t nthin = 0;
+    std::vector<uint32_t> regular(ntris, 0u), thin(ntris, 0u);
+    std::vector<TriGeom> geo(ntris);
+    std::vector<ConeItem> item(ntris);
+    uint32_t nreg = 0, nthin = 0, ndead = 0;
     for (uint32_t g = 0; g < ntris; ++g) {
         pb[g] = padded_box(recs + 3 * (size_t)g);
-        if (thin_triangle(recs + 3 * (size_t)g)) { regular[g] = 0u; thin[g] = 1u; ++nthin; }
+        const TriGeom t = geo[g] = tri_geom(recs + 3 * (size_t)g);
+        if (t.cls == kTriDead) { ++ndead; continue; }
+        item[g] = cone_item(t, g);
+        if (t.cls == kTriRegular) { regular[g] = 1u; ++nreg; } else { thin[g] = 1u; ++nthin; }
     }
-    if (bvh.thin_count != nthin) { why = "thin-triangle count"; return false; }
+    if (bvh.regular_count != nreg || bvh.thin_count != nthin || bvh.dead_count != ndead) { why = "triangle class counts"; return false; }
     if (!validate_walk(recs, 3, ntris, regular, pb, bvh, why)) return false;
-    if (nthin == 0) return bvh.thin_nodes.empty();
-    Bvh t;                                                       // the second hierarchy through the same structural walk
-    t.nodes = bvh.thin_nodes; t.tris = bvh.thin_tris; t.index = bvh.thin_index;
-    if (!validate_walk(recs, 3, ntris, thin, pb, t, why)) { why = "thin hierarchy: " + why; return false; }
+    if (bvh.flat) {                                                          // the thin triangles as a table
+        if (!bvh.lines.empty() || bvh.flat_lines.size() != 2 * (size_t)nthin) { why = "line table size"; return false; }
+        std::vector<uint32_t> seen(ntris, 0u);
+        for (uint32_t k = 0; k < nthin; ++k) {
+            const float4 e = bvh.flat_lines[2 * (size_t)k], v = bvh.flat_lines[2 * (size_t)k + 1];
+            uint32_t g;
+            std::memcpy(&g, &v.w, 4);
+            if (g >= ntris || !thin[g] || seen[g]++) { why = "line table index"; return false; }
+            double dd = 0.0;
+            for (int a = 0; a < 3; ++a) { const double d = (&e.x)[a] - item[g].d[a]; dd += d * d; }
+            if (!(std::sqrt(dd) <= 3e-7 && (double)e.w >= item[g].tol && v.x == (float)item[g].v0[0] && v.y == (float)item[g].v0[1] && v.z == (float)item[g].v0[2])) {
+                why = "line table record " + std::to_string(g); return false;
+            }
+        }
+    } else if (!bvh.flat_lines.empty()) { why = "line table beside the line tree"; return false; }
+    if (!validate_cones(bvh, geo, why)) return false;
+    if (!validate_cone_tree(bvh.planes, true, item, regular, why)) { why = "plane tree: " + why; return false; }
+    if (!bvh.flat && !validate_cone_tree(bvh.lines, false, item, thin, why)) { why = "line tree: " + why; return false; }
     return true;
 }
 

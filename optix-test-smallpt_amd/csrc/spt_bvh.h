@@ -7,15 +7,16 @@
 //
 // Contract (include/smallpt_mi355x.h, spt_set_mesh_accel): the traversal evaluates the SAME triIntersect arithmetic on
 // the triangles it visits and selects by the same rule (smallest t > 0, lowest (instance, triangle) index among equal
-// t), so it returns the exhaustive loop's hit whenever it visits that triangle.  Boxes are padded by a quarter of the
-// triangle's longest edge (+ 1e-4 of its largest coordinate) and the slab tests are widened, which covers every hit
-// whose ray passes within rounding distance of its triangle; triIntersect has no determinant cut-off, so for a ray
-// lying (to ~1e-7 rad) in a triangle's plane it can also report hits with no geometric relation to the triangle, which
-// no bounding volume contains.  The exhaustive kernel therefore stays the default and the parity anchor; tests compare
-// the two on millions of rays, adversarial ones included.
+// t), so it returns the exhaustive loop's hit whenever it visits that triangle -- and since round 4 it provably visits
+// every triangle whose reported key beats or ties the answer (spt_tribvh.h): this spatial hierarchy finds the reports
+// whose error is bounded (its child boxes are inflated per ray), a ball tree over the triangles' PLANES finds the rays
+// that lie in a regular triangle's plane to rounding (triIntersect has no determinant cut-off, scene.cpp:62, and reports
+// noise there), a ball tree over the long edges' LINES finds the thin triangles (needles, zero area) whatever the ray.
 #ifndef SPT_BVH_H
 #define SPT_BVH_H
 #include <hip/hip_runtime.h>
+
+#include "spt_tribvh.h"
 
 #include <cstdint>
 #include <string>
@@ -34,22 +35,29 @@ struct Bvh {
     std::vector<uint32_t> index;      // global (instance-major) triangle index of every leaf-order triangle
     std::vector<uint32_t> always;     // sphere hierarchies: global indices (ascending) of the spheres kept out of the tree
     uint32_t depth = 0, leaves = 0;
-    // Triangle hierarchies: THIN triangles (area <= 2^-10 of the longest edge squared: the needles makeSphereTriMesh puts at the poles,
-    // scene.cpp:13-27) live in a second hierarchy of the same layout that is traversed along the ray's whole LINE without a distance
-    // cut.  triIntersect divides by dot(rd, cross(e1, e2)) (scene.cpp:62), which is rounding noise for such a triangle whatever the ray:
-    // a ray passing within rounding distance of the needle gets a "hit" whose distance has nothing to do with where the needle is, so
-    // the exhaustive loop's answer can only be reproduced by testing the needle whenever the line meets its padded box.
-    std::vector<float4> thin_nodes, thin_tris;
-    std::vector<uint32_t> thin_index;
-    uint32_t thin_count = 0;
+    // Triangle hierarchies (spt_tribvh.h): the spatial tree above holds the REGULAR triangles; `planes` is the cone tree over their planes
+    // (6 float4 per node: {left axis, kappa} {left p, sigma} {right axis, kappa} {right p, sigma} {left tau, left te, right tau, right te}
+    // {left, right, 0, 0}), `lines` the one over the long edges of the THIN triangles (5 float4 per node: {left axis, kappa} {left p, lam}
+    // {right axis, kappa} {right p, lam} {left, right, 0, 0}).  Leaves are single triangles: a negative reference r stands for the GLOBAL
+    // triangle ~r (record 3 * ~r of the scene's table).  Triangles with an edge of length zero are in no structure (never accepted,
+    // spt_tribvh.h (0)).
+    std::vector<float4> planes, lines;
+    // up to kTriFlatLines thin triangles are kept as a table instead of `lines` (spt_tribvh.h (3)): {eh, a} {v0, global index} each
+    std::vector<float4> flat_lines;
+    std::vector<float4> cones;        // spatial tree, 3 float4 per node: {left axis, kappa} {right axis, kappa} {left 1/g_max, left 1.016 e_max, right ..} (spt_tribvh.h (1))
+    uint32_t regular_count = 0, thin_count = 0, dead_count = 0, ball_depth = 0;
+    bool flat = false;                // the thin triangles are a table (flat_lines), not a tree (lines)
 };
-constexpr double kBvhThinRatio = 1.0 / 1024.0;   // |cross(e1, e2)| <= ratio * (longest edge)^2
 
 // recs: ntris x 3 records {v0, n.x} {v1 - v0, n.y} {v2 - v0, n.z}.  Throws std::runtime_error on non-finite vertices.
-void build_bvh(const float4* recs, uint32_t ntris, Bvh& out);
+// form: how the thin triangles are kept -- 0 = by their number (a table up to kTriFlatLines), 1 = table, 2 = tree (tests).
+void build_bvh(const float4* recs, uint32_t ntris, Bvh& out, int form = 0);
 // Structural check used by the CPU tests: every triangle in exactly one leaf, every box contains its subtree's padded
 // triangles, depth bound respected.  Returns false and a reason on failure.
 bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why);
+// The regular triangles whose plane contains the point o to within (B) of spt_tribvh.h (2) (global indices, ascending): what replaces
+// the plane tree for rays that all start at o (a pinhole camera's frame).
+void camera_planes(const float4* recs, uint32_t ntris, const float o[3], std::vector<uint32_t>& out);
 
 // The same hierarchy over a sphere table (SPT_ACCEL_BVH of spt_set_sphere_accel): geom[i] = {centre, r*r}, radius[i] = r.
 // Node boxes are the spheres' own extents (no padding: closest_sphere_bvh inflates every box it tests by a bound on the

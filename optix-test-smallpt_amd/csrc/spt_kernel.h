@@ -1,6 +1,7 @@
 // spt_kernel.h -- launch parameters shared by the kernel TU (hipcc) and the C-ABI TU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "spt_tribvh.h"
 #include <stdint.h>
 
 #define SPT_K_MAX_DEPTH 4096u
@@ -60,9 +61,15 @@ struct MParams {
     const float4* bvh_nodes;       // 4 per node: both children's boxes + their references
     const float4* bvh_tris;        // the records of `tris` in leaf order
     const uint32_t* bvh_index;     // global triangle index of every leaf-order triangle
-    const float4* thin_nodes;      // second hierarchy over the thin triangles (spt_bvh.h), traversed along the whole line; null = none
-    const float4* thin_tris;
-    const uint32_t* thin_index;
+    const float4* bvh_cones;       // 3 per node of the hierarchy: the children's normal cones (spt_tribvh.h (1)); null = SPT_ACCEL_BVH_FAST
+    const float4* plane_nodes;     // cone tree over the regular triangles' planes (spt_tribvh.h (2)); null = none
+    const float4* line_nodes;      // cone tree over the thin triangles' long edges (spt_tribvh.h (3)); null = none or the table below
+    const float4* flat_lines;      // table form of the thin triangles: {eh, a} {v0, index} each; null = none or the tree above
+    uint32_t nthin;
+    // rays of depth 0 of a launch whose camera has ONE origin (pinhole: cam_push = 0) skip the plane tree and test this list instead:
+    // the regular triangles in whose plane that origin lies (spt_bvh.h camera_planes; empty, as a rule).  cam_cull = 0: no such launch
+    const uint32_t* cam_planes;
+    uint32_t ncam, cam_cull;
     // sphere tables through the same kernel (spt_set_sphere_accel): bvh_tris holds one {centre, r*r} per sphere in leaf order,
     // `always` the spheres kept out of the tree; hits take centre / material from KParams::geom / mat
     const uint32_t* always;

@@ -148,74 +148,50 @@ __device__ __forceinline__ uint32_t closest_triangle_few(const float4* __restric
 // segment [0, current nearest] with widened slabs (a box is only skipped when the ray misses it by more than the widening;
 // NaN from 0 * inf drops out of v_min/v_max, which is the conservative side).  A triangle replaces the current hit when its
 // key is smaller, or equal with a lower global index: the (instance, triangle)-ascending strict '<' of the reference's loops.
-// LINE = false: the regular triangles, ray segment [0, current nearest].  LINE = true: the thin triangles (spt_bvh.h), tested
-// whenever the ray's whole LINE meets their padded box -- no sign test, no distance cut: triIntersect's result for a needle is
-// rounding noise (it divides by a determinant that is zero to rounding for every ray), so the exhaustive loop may report such a
-// triangle at any distance, also "in front of" the needle or of a nearer real surface.
-template <bool LINE>
-__device__ __forceinline__ void walk_triangle_bvh(const float4* __restrict__ nodes, const float4* __restrict__ tris, const uint32_t* __restrict__ index,
-                                                  uint32_t* s_stack, f3 ro, f3 rd, f3 iv, uint32_t& near_key, uint32_t& near_tri, float& tcut)
-{
-    uint32_t sp = 0;
-    int cur = 0;                                               // the root is always node 0
-    for (;;) {
-        if (cur >= 0) {
-            const float4* nd = nodes + 4 * (size_t)cur;
-            const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
-            const float lx0 = (a.x - ro.x) * iv.x, lx1 = (a.w - ro.x) * iv.x;
-            const float ly0 = (a.y - ro.y) * iv.y, ly1 = (b.x - ro.y) * iv.y;
-            const float lz0 = (a.z - ro.z) * iv.z, lz1 = (b.y - ro.z) * iv.z;
-            const float rx0 = (b.z - ro.x) * iv.x, rx1 = (c.y - ro.x) * iv.x;
-            const float ry0 = (b.w - ro.y) * iv.y, ry1 = (c.z - ro.y) * iv.y;
-            const float rz0 = (c.x - ro.z) * iv.z, rz1 = (c.w - ro.z) * iv.z;
-            const float ln = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)), __builtin_fminf(lz0, lz1));
-            const float lf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)), __builtin_fmaxf(lz0, lz1));
-            const float rn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)), __builtin_fminf(rz0, rz1));
-            const float rf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)), __builtin_fmaxf(rz0, rz1));
-            bool hl, hr;
-            if (LINE) {                                        // widened by 1e-4 of the parameters' size, whatever their signs
-                hl = ln <= lf + 1e-4f * (__builtin_fabsf(ln) + __builtin_fabsf(lf));
-                hr = rn <= rf + 1e-4f * (__builtin_fabsf(rn) + __builtin_fabsf(rf));
-            } else {
-                hl = (lf >= 0.f) & (ln <= lf * 1.0001f) & (ln <= tcut);
-                hr = (rf >= 0.f) & (rn <= rf * 1.0001f) & (rn <= tcut);
-            }
-            const int lref = __float_as_int(d.x), rref = __float_as_int(d.y);
-            if (hl & hr) {
-                const bool left_first = ln <= rn;
-                s_stack[sp * kMeshBlock + threadIdx.x] = (uint32_t)(left_first ? rref : lref);
-                ++sp;
-                cur = left_first ? lref : rref;
-                continue;
-            }
-            if (hl | hr) { cur = hl ? lref : rref; continue; }
-        } else {
-            const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = code & 7u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4* r = tris + 3 * (size_t)(first + k);
-                float u, v;
-                const float t = tri_test(r[0], r[1], r[2], ro, rd, u, v);
-                const uint32_t key = __float_as_uint(t) - 1u;
-                const uint32_t g = index[first + k];
-                if (key < near_key || (key == near_key && g < near_tri)) {      // key == kMeshInfKey never replaces: near_tri would have to be larger
-                    if (key < kMeshInfKey) { near_key = key; near_tri = g; tcut = t * 1.0001f; }
-                }
-            }
-        }
-        if (sp == 0u) break;
-        --sp;
-        cur = (int)s_stack[sp * kMeshBlock + threadIdx.x];
-    }
-}
+// Since round 4 the query is exhaustive-equivalent for every ray (spt_tribvh.h): the spatial walk inflates the child boxes per ray and
+// finds every report whose error is bounded; the rays for which triIntersect's determinant is zero to rounding -- in a regular
+// triangle's plane, or near the supporting line of a thin triangle's long edge -- find those triangles through two ball trees in
+// plane space and line space.  The walks and node tests are the host / device functions of spt_tribvh.h, which the CPU harness
+// (tests/sanitize/tribvh_main.cpp) runs against the exhaustive loop.
+struct LdsStack {
+    uint32_t* base;                                            // entry e of thread t at base[e * kMeshBlock + t]: conflict-free
+    __device__ __forceinline__ void push(uint32_t sp, uint32_t v) { base[sp * kMeshBlock + threadIdx.x] = v; }
+    __device__ __forceinline__ uint32_t pop(uint32_t sp) const { return base[sp * kMeshBlock + threadIdx.x]; }
+};
 
-__device__ __forceinline__ uint32_t closest_triangle_bvh(const MParams& M, uint32_t* s_stack, bool active, f3 ro, f3 rd, float& t_out)
+__device__ __forceinline__ uint32_t closest_triangle_bvh(const MParams& M, uint32_t* s_stack, bool active, bool camera_ray, f3 ro, f3 rd, float& t_out)
 {
     uint32_t near_key = kMeshInfKey, near_tri = 0xFFFFFFFFu;
     if (active) {
-        const f3 iv = mk(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));   // 1 ulp; inside the widening
         float tcut = 1e20f;                                        // widened distance of the current nearest hit
-        walk_triangle_bvh<false>(M.bvh_nodes, M.bvh_tris, M.bvh_index, s_stack, ro, rd, iv, near_key, near_tri, tcut);
-        if (M.thin_nodes) walk_triangle_bvh<true>(M.thin_nodes, M.thin_tris, M.thin_index, s_stack, ro, rd, iv, near_key, near_tri, tcut);
+        LdsStack st{s_stack};
+        auto consider = [&](const float4* r, uint32_t g) {
+            float u, v;
+            const float t = tri_test(r[0], r[1], r[2], ro, rd, u, v);
+            const uint32_t key = __float_as_uint(t) - 1u;
+            if (key < near_key || (key == near_key && g < near_tri)) {          // key == kMeshInfKey never replaces: near_tri would have to be larger
+                if (key < kMeshInfKey) { near_key = key; near_tri = g; tcut = t * 1.0001f; }
+            }
+        };
+        TriQuery q;
+        tri_query(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, q);
+        const float ivx = __builtin_amdgcn_rcpf(rd.x), ivy = __builtin_amdgcn_rcpf(rd.y), ivz = __builtin_amdgcn_rcpf(rd.z);   // 1 ulp; inside the widening
+        auto leaf = [&](uint32_t first, uint32_t cnt) {
+            for (uint32_t k = 0; k < cnt; ++k) consider(M.bvh_tris + 3 * (size_t)(first + k), M.bvh_index[first + k]);
+        };
+        auto by_index = [&](uint32_t g) { consider(M.tris + 3 * (size_t)g, g); };
+        if (!M.bvh_cones) {                                        // SPT_ACCEL_BVH_FAST: the plain hierarchy (documented exceptions)
+            tri_walk_boxes<false>(M.bvh_nodes, nullptr, ro.x, ro.y, ro.z, ivx, ivy, ivz, q.h[0], q.h[1], q.h[2], tcut, st, leaf);
+        } else {
+            tri_walk_boxes<true>(M.bvh_nodes, M.bvh_cones, ro.x, ro.y, ro.z, ivx, ivy, ivz, q.h[0], q.h[1], q.h[2], tcut, st, leaf);
+            if (camera_ray) {                                      // one origin for the whole frame: the planes through it are listed (spt_bvh.h camera_planes)
+                for (uint32_t k = 0; k < M.ncam; ++k) by_index(M.cam_planes[k]);
+            } else if (M.plane_nodes) {
+                tri_walk_planes(M.plane_nodes, q, st, by_index);
+            }
+            if (M.flat_lines) tri_scan_lines(M.flat_lines, M.nthin, q, st, by_index);
+            else if (M.line_nodes) tri_walk_lines(M.line_nodes, q, st, by_index);
+        }
     }
     t_out = __uint_as_float(near_key + 1u);
     return near_tri;
@@ -351,7 +327,7 @@ __global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const 
     f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (active) { ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]); rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]); }
     float t;
-    const uint32_t tri = BVH ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), active, ro, rd, t)
+    const uint32_t tri = BVH ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), active, false, ro, rd, t)
                              : closest_triangle(M.tris, M.ntris, s_tile, active, ro, rd, t);
     if (!active) return;
     float* h = hits + 11 * i;
@@ -500,7 +476,7 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
         }
         // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
         const uint32_t tri = GEOM == 2 ? (coop ? coop_tri : closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t))
-                           : GEOM == 1 ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t)
+                           : GEOM == 1 ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, M.cam_cull != 0u && p.depth == 0u, p.o, p.d, t)
                            : nalive <= (uint32_t)kFewRays ? closest_triangle_few(M.tris, M.ntris, s_tile, nalive, alive, p.o, p.d, t)
                                        : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
         if (alive) {

@@ -81,8 +81,8 @@ public:
         }
         check(spt_set_meshes(ctx_, ms.data(), (uint32_t)ms.size(), mats.data()));
     }
-    // CPUIntersector (every triangle: SPT_ACCEL_EXHAUSTIVE, the default) or the OptixIntersector's acceleration structure
-    // (rtpModelUpdate, smallpt.cpp:520-530: SPT_ACCEL_BVH); contract in include/smallpt_mi355x.h
+    // the OptixIntersector's acceleration structure (rtpModelUpdate, smallpt.cpp:520-530: SPT_ACCEL_BVH, the default since round 4 -- the same
+    // Hit as the loop for every ray) or the CPUIntersector's loop over every triangle (SPT_ACCEL_EXHAUSTIVE); contract in include/smallpt_mi355x.h
     void setMeshAccel(int accel) { check(spt_set_mesh_accel(ctx_, accel)); }
     // the same switch for sphere tables above 24 spheres (exhaustive-equivalent by construction, include/smallpt_mi355x.h)
     void setSphereAccel(int accel) { check(spt_set_sphere_accel(ctx_, accel)); }

@@ -5,7 +5,7 @@
 //
 //   smallpt_mi355x [spp] [--scene file.json | shipped-meshes] [--size WxH] [--seed N] [--out image.ppm] [--device D]
 //                  [--dump-scene out.json] [--parse-only]
-//                  [--accel grid|bvh|exhaustive]               closest hit of sphere tables above 24 (default grid) / mesh scenes (default exhaustive)
+//                  [--accel grid|bvh|bvh-fast|exhaustive]             closest hit of sphere tables above 24 (default grid) / mesh scenes (default bvh)
 //                  [--devices 0,1,...] [--self-exchange]      row bands over several GPUs + RCCL exchange (MultiRenderer)
 //   smallpt_mi355x [spp] --viewer [--frames N] [--request JSON] [--frames-after M] [--threaded] [--org x,y,z]
 //                  [--pipeline L] [--bench-frames N]           L frames in flight (one context each); frames/s of N frames as JSON
@@ -32,7 +32,7 @@ int main(int argc, char* argv[])
 {
     int spp = 4, w = 256, h = 256, device = 0;       // smallpt.cpp:274-276 defaults
     unsigned long long seed = 0;
-    int accel = -1;                                  // -1: the library's defaults (spheres: grid; meshes: exhaustive)
+    int accel = -1;                                  // -1: the library's defaults (spheres: grid; meshes: bvh)
     int pipeline = 1, bench_frames = 0;
     double watchdog = 0.0;                           // test hook: kernel watchdog in seconds (csrc/spt_internal.h)
     std::string scene_path, out_path = "image.ppm", dump_path;
@@ -62,7 +62,7 @@ int main(int argc, char* argv[])
                 return 0;
             } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
         }
-        else if (a == "--accel") { const std::string m = next(); if (m == "bvh") accel = SPT_ACCEL_BVH; else if (m == "exhaustive") accel = SPT_ACCEL_EXHAUSTIVE; else if (m == "grid") accel = SPT_ACCEL_GRID; else { std::fprintf(stderr, "--accel grid|bvh|exhaustive\n"); return 2; } }
+        else if (a == "--accel") { const std::string m = next(); if (m == "bvh") accel = SPT_ACCEL_BVH; else if (m == "bvh-fast") accel = SPT_ACCEL_BVH_FAST; else if (m == "exhaustive") accel = SPT_ACCEL_EXHAUSTIVE; else if (m == "grid") accel = SPT_ACCEL_GRID; else { std::fprintf(stderr, "--accel grid|bvh|bvh-fast|exhaustive\n"); return 2; } }
         else if (a == "--pipeline") { pipeline = std::atoi(next()); if (pipeline < 1 || pipeline > 8) { std::fprintf(stderr, "--pipeline 1..8\n"); return 2; } }
         else if (a == "--bench-frames") bench_frames = std::atoi(next());
         else if (a == "--watchdog") watchdog = std::atof(next());

@@ -14,7 +14,7 @@ from .scene import HIT_DTYPE, RAY_DTYPE, SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
 FLAG_ONE_SHOT = 2          # scheduling only: no dispatch order used or recorded for this launch (include/smallpt_mi355x.h)
-ACCEL_EXHAUSTIVE, ACCEL_BVH, ACCEL_GRID = 0, 1, 2
+ACCEL_EXHAUSTIVE, ACCEL_BVH, ACCEL_GRID, ACCEL_BVH_FAST = 0, 1, 2, 3
 
 
 class SptError(RuntimeError):
@@ -143,8 +143,9 @@ class Renderer:
         self._state_version += 1
 
     def set_mesh_accel(self, accel):
-        """ACCEL_EXHAUSTIVE (default: every triangle, bit-identical to the reference's loops) or ACCEL_BVH (the role of the
-        reference's OptiX Prime model, smallpt.cpp:475-603; contract in include/smallpt_mi355x.h)."""
+        """ACCEL_BVH (default since round 4: the role of the reference's OptiX Prime model, smallpt.cpp:475-603; the exhaustive loop's
+        Hit for every ray, include/smallpt_mi355x.h), ACCEL_EXHAUSTIVE (every triangle, the reference's CPU loops: the parity anchor) or
+        ACCEL_BVH_FAST (the plain hierarchy of rounds 2-3: several times faster, but rays lying in a triangle's plane to rounding may differ)."""
         self._check(self._lib.spt_set_mesh_accel(self._h, int(accel)))
         self._state["mesh_accel"] = int(accel)
         self._state_version += 1

@@ -47,12 +47,14 @@ def run(name, meshes, mats, w, h, samps, camera, rows, accel=0):
     return out
 
 
-def viewer_loop(name, meshes, mats, frames=200):
+def viewer_loop(name, meshes, mats, frames=200, pinhole=False, accel=None):
     import torch
     r = pkg.Renderer(0)
-    r.set_mesh_accel(pkg.ACCEL_BVH)
+    r.set_mesh_accel(pkg.ACCEL_BVH if accel is None else accel)
     r.set_meshes(meshes, mats)
-    cam = pkg.smallpt_camera(1280, 720)
+    # pinhole: the interactive driver's Camera (smallpt.cpp:607-641) at the smallpt camera's position and direction -- one origin for
+    # the whole frame, so the rays of depth 0 test the list of planes through it instead of walking the plane tree
+    cam = pkg.pinhole_camera(vz=(0, -0.042573, -0.999093), org=(50, 52, 295.6)) if pinhole else pkg.smallpt_camera(1280, 720)
     prog = pkg.ProgressiveRenderer(r, 1280, 720, 1, camera=cam)
     for _ in range(10):
         prog.step()
@@ -62,7 +64,7 @@ def viewer_loop(name, meshes, mats, frames=200):
         prog.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / frames
-    out = {"config": name, "accel": "bvh", "triangles": sum(m.triangle_count for m in meshes), "image": "1280x720", "spp": 4,
+    out = {"config": name, "accel": {None: "bvh", 0: "exhaustive", 1: "bvh", 3: "bvh-fast"}[accel], "camera": "pinhole" if pinhole else "smallpt", "triangles": sum(m.triangle_count for m in meshes), "image": "1280x720", "spp": 4,
            "frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3), "accum_nonzero": bool(float(prog.accum.abs().sum()) > 0)}
     print(json.dumps(out), flush=True)
     r.close()
@@ -85,6 +87,8 @@ def main():
                     "0.5 M triangles per ray on the CPU)", big, mats, 1280, 720, 1, None, [], accel=1))
     rows.append(viewer_loop("f3 + f4: the viewer's render loop (ProgressiveRenderer, smallpt.cpp:895-942) on the shipped mesh scene, 1280x720, "
                             "1 sample per jitter cell per frame, hierarchy", meshes, mats))
+    for accel, frames in ((pkg.ACCEL_BVH, 200), (pkg.ACCEL_BVH_FAST, 200), (pkg.ACCEL_EXHAUSTIVE, 20)):
+        rows.append(viewer_loop("f3 + f4: the same loop with the interactive driver's pinhole Camera (one origin per frame)", meshes, mats, frames=frames, pinhole=True, accel=accel))
     meshes, mats = pkg.single_triangle_scene()
     rows.append(run("f4: SingleTriangleScene of main(), viewer camera", meshes, mats, 1280, 720, 1, pkg.pinhole_camera(), [300, 500]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
