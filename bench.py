@@ -234,7 +234,42 @@ def extra_mesh_config(pkg, samps, reps=3, bvh=False):
     return res
 
 
-EXTRAS = ("config3", "config5", "mesh_4spp", "mesh_256spp", "mesh_4spp_bvh", "mesh_256spp_bvh")
+def extra_mesh_viewer(pkg, frames=100):
+    """The viewer's render loop (ProgressiveRenderer, smallpt.cpp:895-942: one sample per jitter cell per frame, pinhole Camera :607-641) on the
+    reference's shipped mesh scene at 1280x720, through the library's default (SPT_ACCEL_BVH: the exhaustive loop's Hit for every ray), the
+    plain hierarchy (SPT_ACCEL_BVH_FAST) and the exhaustive loop; the accumulators of the first two after 8 frames against the third's."""
+    import time
+    import torch
+    meshes = [pkg.make_sphere_trimesh((50, 40.8, 81.6), 10.0), pkg.make_sphere_trimesh((50, 681.6 - .27, 81.6), 600.0)]
+    mats = [((0, 0, 0), (.75, .25, .25), pkg.DIFF), ((1, 1, 1), (0, 0, 0), pkg.DIFF)]
+    cam = pkg.pinhole_camera(vz=(0, -0.042573, -0.999093), org=(50, 52, 295.6))
+    res = {"workload": "the reference's shipped scene (2 spheres x 4096 triangles), 1280x720, 1 sample per jitter cell per frame, pinhole camera at the "
+                       "smallpt camera's position, serial frames", "unit": "frames/s"}
+    accs = {}
+    for name, accel, n in (("bvh", pkg.ACCEL_BVH, frames), ("bvh_fast", pkg.ACCEL_BVH_FAST, frames), ("exhaustive", pkg.ACCEL_EXHAUSTIVE, max(8, frames // 10))):
+        r = pkg.Renderer(torch.cuda.current_device())
+        r.set_mesh_accel(accel)
+        r.set_meshes(meshes, mats)
+        prog = pkg.ProgressiveRenderer(r, 1280, 720, 1, camera=cam)
+        for _ in range(8):
+            prog.step()
+        prog.flush()
+        accs[name] = prog.accum.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            prog.step()
+        prog.flush()
+        torch.cuda.synchronize()
+        res[name] = round(n / (time.perf_counter() - t0), 1)
+        prog.close(); r.close()
+    res["accum_identical_to_exhaustive"] = {k: bool(torch.equal(accs[k], accs["exhaustive"])) for k in ("bvh", "bvh_fast")}
+    res["note"] = ("bvh = the default: exhaustive-equivalent for every ray (csrc/spt_tribvh.h); a pinhole frame tests the planes through the camera's origin "
+                   "instead of walking the plane tree.  bvh_fast = the plain hierarchy (rays lying in a triangle's plane to rounding may differ)")
+    return res
+
+
+EXTRAS = ("config3", "config5", "mesh_4spp", "mesh_256spp", "mesh_4spp_bvh", "mesh_256spp_bvh", "mesh_viewer")
 
 
 def run_extra(pkg, name):
@@ -250,6 +285,8 @@ def run_extra(pkg, name):
         return extra_mesh_config(pkg, 1, bvh=True)
     if name == "mesh_256spp_bvh":
         return extra_mesh_config(pkg, 64, bvh=True)
+    if name == "mesh_viewer":
+        return extra_mesh_viewer(pkg)
     raise SystemExit(f"unknown extra {name}")
 
 
