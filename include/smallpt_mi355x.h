@@ -128,22 +128,30 @@ typedef struct spt_hit { float dist; uint32_t instId; uint32_t triId; float x[3]
  * un-normalised vertex normal).  spt_set_scene switches back to spheres. */
 int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
 
-/* How the closest hit of a mesh scene is found.  Both modes return the same Hit for EVERY ray (since round 4).
+/* How the closest hit of a mesh scene is found.  SPT_ACCEL_BVH and SPT_ACCEL_EXHAUSTIVE return the same Hit for EVERY ray (since round 4).
  *   SPT_ACCEL_BVH (default since round 4): the role of the OptiX Prime model/query of the reference's GPU intersector
  *     (smallpt.cpp:475-603, the intersector the reference actually runs, :605): structures built over the triangles when the
  *     meshes are set.  The triangles they reach go through the same triIntersect arithmetic and the same selection (smallest
  *     dist > 0, lowest (instance, triangle) among equal dist) as the exhaustive loop, and they provably reach every triangle whose
- *     report beats or ties the answer (csrc/spt_tribvh.h): a bounding-volume hierarchy whose boxes are inflated per ray by the
- *     error bound of a report; and, because triIntersect has no determinant cut-off (scene.cpp:62) and reports rounding noise
- *     when dot(rd, cross(e1, e2)) is zero to rounding -- a "hit" no bounding volume contains --, a ball tree over the triangles'
- *     PLANES that finds the triangles in whose plane the ray lies, and one over the long edges' LINES of thin triangles (the
- *     needles makeSphereTriMesh puts at the poles: their normal is noise for every ray) that finds the needles whose supporting
- *     line the ray's line crosses, wherever along it.  Rounds 2 and 3 documented those rays as exceptions (18 of 668 000 test
- *     rays); tests/test_meshes.py now requires 0 differences on 700 000 random and adversarial rays, the CPU harness
- *     tests/sanitize/tribvh_main.cpp runs the same walk functions against the exhaustive loop.  A ray that starts hundreds of
- *     scene sizes away degrades towards the exhaustive loop's cost (the error bound grows with the distance), never in result.
+ *     report beats or ties the answer (csrc/spt_tribvh.h): a bounding-volume hierarchy whose boxes are inflated per ray and per
+ *     node by the error bound of a report (it knows a cone of the normals below each node); and, because triIntersect has no
+ *     determinant cut-off (scene.cpp:62) and reports rounding noise when dot(rd, cross(e1, e2)) is zero to rounding -- a "hit" no
+ *     bounding volume contains --, a tree over the triangles' PLANES that finds the triangles in whose plane the ray lies, and a
+ *     table (a tree beyond 16 384) of the long edges' LINES of thin triangles (the needles makeSphereTriMesh puts at the poles:
+ *     their normal is noise for every ray) that finds the needles whose supporting line the ray's line crosses, wherever along
+ *     it.  Rounds 2 and 3 documented those rays as exceptions (18 of 668 000 test rays); tests/test_meshes.py now requires 0
+ *     differences on 700 000 random and adversarial rays, the CPU harness tests/sanitize/tribvh_main.cpp runs the same walk
+ *     functions against the exhaustive loop.  A launch whose camera has one origin (spt_camera_pinhole: push = 0) lists the
+ *     triangles in whose plane that origin lies once and its rays of depth 0 test the list instead of walking the plane tree.
+ *     Cost, shipped scene (8192 triangles), 1280 x 720 x 4 spp: 4.4 ms per pinhole frame, 12 ms with the smallpt camera (an
+ *     origin per ray), against 25-29 ms through the exhaustive loop.  A ray that starts hundreds of scene sizes away degrades
+ *     towards the exhaustive loop's cost (the error bound grows with the distance), never in result.
  *   SPT_ACCEL_EXHAUSTIVE: every triangle of every instance is tested, as CPUIntersector::intersect does (smallpt.cpp:443-458 over
  *     scene.cpp:95-116): the parity anchor.
+ *   SPT_ACCEL_BVH_FAST (opt-in): the bounding-volume hierarchy alone, as in rounds 2-3 -- 2.6 ms for the pinhole frame above.  It
+ *     returns the exhaustive Hit whenever the winning triangle's padded box is crossed within the current nearest distance; a ray
+ *     lying (to ~1e-7 rad) in a triangle's plane, or crossing a needle's supporting line, may lose the noise "hit" the reference's
+ *     arithmetic reports there.  Rendered images have never met the condition (tests compare them), constructed rays do.
  * Applies to spt_trace_rays and to spt_render* / spt_progressive_* of a mesh scene; may be changed at any time. */
 #define SPT_ACCEL_EXHAUSTIVE 0
 #define SPT_ACCEL_BVH        1
