@@ -141,10 +141,10 @@ int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const 
  *     their normal is noise for every ray) that finds the needles whose supporting line the ray's line crosses, wherever along
  *     it.  Rounds 2 and 3 documented those rays as exceptions (18 of 668 000 test rays); tests/test_meshes.py now requires 0
  *     differences on 700 000 random and adversarial rays, the CPU harness tests/sanitize/tribvh_main.cpp runs the same walk
- *     functions against the exhaustive loop.  A launch whose camera has one origin (spt_camera_pinhole: push = 0) lists the
- *     triangles in whose plane that origin lies once and its rays of depth 0 test the list instead of walking the plane tree.
- *     Cost, shipped scene (8192 triangles), 1280 x 720 x 4 spp: 4.4 ms per pinhole frame, 12 ms with the smallpt camera (an
- *     origin per ray), against 25-29 ms through the exhaustive loop.  A ray that starts hundreds of scene sizes away degrades
+ *     functions against the exhaustive loop.  A render launch lists the triangles in whose plane the camera's origin lies once
+ *     (the lines of all its rays of depth 0 pass through that point) and those rays test the list instead of walking the plane
+ *     tree.  Cost, shipped scene (8192 triangles), 1280 x 720 x 4 spp: 4.4 ms per pinhole frame, 6.2 ms with the smallpt camera,
+ *     against 25-29 ms through the exhaustive loop; spt_trace_rays_device 0.37 Grays/s against 0.125.  A ray that starts hundreds of scene sizes away degrades
  *     towards the exhaustive loop's cost (the error bound grows with the distance), never in result.
  *   SPT_ACCEL_EXHAUSTIVE: every triangle of every instance is tested, as CPUIntersector::intersect does (smallpt.cpp:443-458 over
  *     scene.cpp:95-116): the parity anchor.

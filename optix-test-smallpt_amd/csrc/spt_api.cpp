@@ -75,7 +75,7 @@ struct spt_ctx {
     bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
     float4* d_bvh_nodes = nullptr; float4* d_bvh_tris = nullptr; uint32_t* d_bvh_index = nullptr;
     float4* d_flat_lines = nullptr; uint32_t nthin = 0; bool bvh_flat = false;     // thin triangles as a table (spt_tribvh.h (3))
-    uint32_t* d_cam_planes = nullptr; uint32_t ncam = 0, cam_cap = 0; float cam_key[3] = {0, 0, 0}; bool cam_valid = false;   // spt_bvh.h camera_planes of the last pinhole origin
+    uint32_t* d_cam_planes = nullptr; uint32_t ncam = 0, cam_cap = 0; float cam_key[4] = {0, 0, 0, 0}; bool cam_valid = false;   // spt_bvh.h camera_planes of the last pinhole origin
     float4* d_bvh_cones = nullptr; float4* d_plane_nodes = nullptr; float4* d_line_nodes = nullptr; bool have_planes = false, have_lines = false;   // spt_tribvh.h
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     uint32_t ntris = 0, ninst = 0;
@@ -1000,13 +1000,17 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         } else {
             P.n = 0; P.n_pad = 1; P.geom = nullptr; P.mat = nullptr;
             M = mesh_params(c);
-            if (M.plane_nodes && cam->push == 0.0f) {
-                // a pinhole camera: every ray of depth 0 starts at cam->origin, and a ray can only be reported by a regular triangle through
-                // a determinant that is zero to rounding if its ORIGIN lies in that triangle's plane (spt_tribvh.h (2), condition (B)):
-                // those triangles are listed once per camera position (none, as a rule) and the camera rays skip the plane tree
-                if (!c->cam_valid || std::memcmp(c->cam_key, cam->origin, sizeof c->cam_key) != 0) {
+            if (M.plane_nodes) {
+                // every ray of depth 0 lies on a line through cam->origin and starts at most |push| |d| from it (push = 0: a pinhole
+                // camera, every ray starts there), and a ray can only be reported by a regular triangle through a determinant that is
+                // zero to rounding if its origin lies in that triangle's plane (spt_tribvh.h (2), condition (B)): those triangles are
+                // listed once per camera (none, as a rule) and the camera rays skip the plane tree
+                auto norm3 = [](const float* v) { return std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); };
+                const float extra = (float)(std::fabs((double)cam->push) * (norm3(cam->dir) + 1.1 * (norm3(cam->cx) + norm3(cam->cy))) * 1.01);
+                const float key[4] = {cam->origin[0], cam->origin[1], cam->origin[2], extra};
+                if (!c->cam_valid || std::memcmp(c->cam_key, key, sizeof c->cam_key) != 0) {
                     std::vector<uint32_t> list;
-                    spt::camera_planes(c->h_tris.data(), c->ntris, cam->origin, list);
+                    spt::camera_planes(c->h_tris.data(), c->ntris, cam->origin, extra, list);
                     if (list.size() > c->cam_cap) {
                         if (c->d_cam_planes) (void)hipFree(c->d_cam_planes);
                         c->d_cam_planes = nullptr; c->cam_cap = 0;
@@ -1016,7 +1020,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
                     if (!list.empty()) SPT_HIP(c, hipMemcpyAsync(c->d_cam_planes, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
                     if (!list.empty()) SPT_HIP(c, hipStreamSynchronize(st));           // (the list is a local)
                     c->ncam = (uint32_t)list.size();
-                    std::memcpy(c->cam_key, cam->origin, sizeof c->cam_key);
+                    std::memcpy(c->cam_key, key, sizeof c->cam_key);
                     c->cam_valid = true;
                 }
                 M.cam_planes = c->d_cam_planes; M.ncam = c->ncam; M.cam_cull = 1u;

@@ -517,21 +517,26 @@ void build_bvh(const float4* recs, uint32_t ntris, Bvh& out, int form)
     out.ball_depth = std::max(planes.depth, lines.depth);
 }
 
-// The regular triangles in whose plane the point `o` lies to within condition (B) of spt_tribvh.h (2): the only ones a ray that STARTS
-// at o can be reported by through a determinant that is zero to rounding.  For the rays of a pinhole camera -- one origin for a whole
-// frame -- this short list (empty, as a rule) replaces the walk of the plane tree.
-void camera_planes(const float4* recs, uint32_t ntris, const float o[3], std::vector<uint32_t>& out)
+// The regular triangles in whose plane the point `o` lies to within condition (B) of spt_tribvh.h (2), for rays whose LINES pass through
+// o and whose origins are at most `extra` away from it along the ray: the only triangles such a ray can be reported by through a
+// determinant that is zero to rounding.  (B) holds at the ray's origin ro = o + s d, |s| <= extra: |nh.(ro - v0)| <= tau (R_ro + 2 e),
+// R_ro <= R + extra; with (A), |nh.d| < tau, moving back to o costs tau extra more:  |nh.(o - v0)| <= tau (R + 2 e + 2 extra); the
+// float evaluation of ro = o + d push and of the normalised direction moves the line by 4 u (|o| + extra) at most.  For the rays
+// of depth 0 of a frame -- pinhole camera: extra = 0; smallpt camera: extra = 140 |d| -- this short list (empty, as a rule) replaces
+// the walk of the plane tree.
+void camera_planes(const float4* recs, uint32_t ntris, const float o[3], float extra, std::vector<uint32_t>& out)
 {
     out.clear();
+    const double x = std::fabs((double)extra);
+    const double slack = 16.0 * 0x1p-24 * (std::max({std::fabs((double)o[0]), std::fabs((double)o[1]), std::fabs((double)o[2])}) + x);
     for (uint32_t g = 0; g < ntris; ++g) {
         const TriGeom t = tri_geom(recs + 3 * (size_t)g);
         if (t.cls != kTriRegular) continue;
         const double r[3] = {(double)o[0] - t.v0[0], (double)o[1] - t.v0[1], (double)o[2] - t.v0[2]};
         const double R = std::sqrt(dot3(r, r)), e = std::max(t.l1, t.l2), tau = kTriBand * t.g;
-        if (!(std::fabs(dot3(t.n, r)) / t.nn > tau * (R + 2.0 * e) * (1.0 + 0x1p-9) + 1e-30)) out.push_back(g);      // (NaN origins list everything)
+        if (!(std::fabs(dot3(t.n, r)) / t.nn > tau * (R + 2.0 * e + 2.0 * x) * (1.0 + 0x1p-9) + slack)) out.push_back(g);      // (NaN origins list everything)
     }
 }
-
 
 // Box of a sphere, rounded outward, NOT padded: the traversal inflates node boxes per ray (spt_mesh.hip, closest_sphere_bvh)
 static Box sphere_box(const float4 g, float radius)

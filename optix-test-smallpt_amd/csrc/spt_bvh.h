@@ -56,8 +56,9 @@ void build_bvh(const float4* recs, uint32_t ntris, Bvh& out, int form = 0);
 // triangles, depth bound respected.  Returns false and a reason on failure.
 bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::string& why);
 // The regular triangles whose plane contains the point o to within (B) of spt_tribvh.h (2) (global indices, ascending): what replaces
-// the plane tree for rays that all start at o (a pinhole camera's frame).
-void camera_planes(const float4* recs, uint32_t ntris, const float o[3], std::vector<uint32_t>& out);
+// the plane tree for rays whose lines all pass through o and start at most `extra` from it (the rays of depth 0 of a frame: pinhole
+// camera extra = 0, smallpt camera extra = push * |d|max).
+void camera_planes(const float4* recs, uint32_t ntris, const float o[3], float extra, std::vector<uint32_t>& out);
 
 // The same hierarchy over a sphere table (SPT_ACCEL_BVH of spt_set_sphere_accel): geom[i] = {centre, r*r}, radius[i] = r.
 // Node boxes are the spheres' own extents (no padding: closest_sphere_bvh inflates every box it tests by a bound on the

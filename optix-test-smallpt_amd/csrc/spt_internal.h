@@ -63,9 +63,11 @@ int  spt_selftest_math(spt_ctx* ctx, int op, const float* in, float* out, uint32
 int  spt_selftest_range(spt_ctx* ctx, int op, uint32_t first, uint32_t count, uint64_t* mismatches, uint32_t* first_bad);
 
 /* Host-only self-test of the SPT_ACCEL_BVH builder (csrc/spt_bvh.cpp; no device call, runs without a GPU): builds the
- * hierarchy over the meshes' triangles and checks that every triangle sits in exactly one leaf, that every box contains
- * the padded triangles below it and that no reference lies deeper than the 32-entry traversal stack allows.
- * out4 = {nodes, leaves, depth, triangles of the main hierarchy (thin triangles -- the pole needles of makeSphereTriMesh -- sit in a second one)};
+ * structures of csrc/spt_tribvh.h over the meshes' triangles and checks that every REGULAR triangle sits in exactly one leaf of the
+ * spatial hierarchy and of the plane tree, every THIN one in the line table / tree, that every ancestor's box, normal cone, sigma / tau /
+ * te (planes) or lam (lines) covers it, and that no reference lies deeper than the 32-entry traversal stack allows.
+ * out4 = {nodes, leaves, depth of the spatial hierarchy, regular triangles (thin ones -- the pole needles of makeSphereTriMesh -- and
+ * triangles with an edge of length zero are the rest)};
  * returns 0 = valid, 2 = invalid (reason in `why`), 1 = builder error. */
 int  spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, char* why, uint32_t why_len);
 /* The same for the sphere hierarchy of spt_set_sphere_accel; out4 = {nodes, leaves, depth, always-tested spheres}. */

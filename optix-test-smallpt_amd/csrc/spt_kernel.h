@@ -66,8 +66,8 @@ struct MParams {
     const float4* line_nodes;      // cone tree over the thin triangles' long edges (spt_tribvh.h (3)); null = none or the table below
     const float4* flat_lines;      // table form of the thin triangles: {eh, a} {v0, index} each; null = none or the tree above
     uint32_t nthin;
-    // rays of depth 0 of a launch whose camera has ONE origin (pinhole: cam_push = 0) skip the plane tree and test this list instead:
-    // the regular triangles in whose plane that origin lies (spt_bvh.h camera_planes; empty, as a rule).  cam_cull = 0: no such launch
+    // rays of depth 0 of a render launch (their lines all pass through the camera's origin) skip the plane tree and test this list instead:
+    // the regular triangles in whose plane that origin lies (spt_bvh.h camera_planes; empty, as a rule).  cam_cull = 0: spt_trace_rays
     const uint32_t* cam_planes;
     uint32_t ncam, cam_cull;
     // sphere tables through the same kernel (spt_set_sphere_accel): bvh_tris holds one {centre, r*r} per sphere in leaf order,

@@ -291,9 +291,10 @@ int main(int argc, char** argv)
                                 names[r.family].c_str(), r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, k0, t0, k1, t1);
             }
         }
-        // pinhole cameras: one origin per batch -- some of them placed IN a triangle's plane --, the plane tree replaced by the origin's list
+        // cameras: one point per batch that every ray's line passes through -- most of them placed IN a triangle's plane --, rays starting
+        // there (pinhole) or pushed along their direction (smallpt camera), the plane tree replaced by the point's list
         {
-            names.push_back("pinhole camera (origin's planes listed)");
+            names.push_back("camera rays (the planes through the camera point listed)");
             bad.push_back(0); hits.push_back(0); fcost.emplace_back();
             const int fam = (int)names.size() - 1;
             std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -304,12 +305,17 @@ int main(int argc, char** argv)
                 V3 o = a + e1 * (3.f * U(rng)) + e2 * (3.f * U(rng));                     // in the plane of a triangle, beside it
                 if (c % 3 == 0) o = o + V3{U(rng), U(rng), U(rng)} * (0.5f * std::sqrt(dot(e1, e1)));   // ... or not
                 const float of[3] = {o.x, o.y, o.z};
+                const float push = c % 2 ? 0.f : 1.4f * std::sqrt(dot(e1, e1));           // pinhole, or the smallpt camera's ro = o + d push
                 std::vector<uint32_t> list;
-                spt::camera_planes(s.recs.data(), s.ntris(), of, list);
+                spt::camera_planes(s.recs.data(), s.ntris(), of, push * 1.3f, list);
+                const V3 o_cam = o;
                 for (size_t k = 0; k < per_cam; ++k) {
-                    V3 d;
-                    if (k % 2) { const float u = U(rng), v = U(rng); d = normalized(e1 * u + e2 * v); }      // in that plane
-                    else d = normalized(V3{U(rng), U(rng), U(rng)});
+                    V3 dd;
+                    if (k % 2) { const float u = U(rng), v = U(rng); dd = normalized(e1 * u + e2 * v); }     // in that plane
+                    else dd = normalized(V3{U(rng), U(rng), U(rng)});
+                    dd = dd * (1.f + 0.25f * U(rng));                                        // |d| <= 1.25 < 1.3
+                    const V3 d = normalized(dd);
+                    o = o_cam + dd * push;
                     uint32_t k0, t0, k1, t1;
                     closest_exhaustive(s, o, d, k0, t0);
                     closest_bvh(s, bvh, o, d, k1, t1, cost, &list);
