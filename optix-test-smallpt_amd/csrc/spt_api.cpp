@@ -74,7 +74,7 @@ struct spt_ctx {
     int accel = SPT_ACCEL_BVH;             // mesh scenes (spt_set_mesh_accel): exhaustive-equivalent for every ray since round 4 (spt_tribvh.h)
     bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
     float4* d_bvh_nodes = nullptr; float4* d_bvh_tris = nullptr; uint32_t* d_bvh_index = nullptr;
-    float4* d_flat_lines = nullptr; uint32_t nthin = 0; bool bvh_flat = false;     // thin triangles as a table (spt_tribvh.h (3))
+    float4* d_flat_lines = nullptr; uint32_t* d_flat_line_index = nullptr; uint32_t nline_slots = 0; bool bvh_flat = false;     // thin triangles as a table (spt_tribvh.h (3))
     uint32_t* d_cam_planes = nullptr; uint32_t ncam = 0, cam_cap = 0; float cam_key[4] = {0, 0, 0, 0}; bool cam_valid = false;   // spt_bvh.h camera_planes of the last pinhole origin
     float4* d_bvh_cones = nullptr; float4* d_plane_nodes = nullptr; float4* d_line_nodes = nullptr; bool have_planes = false, have_lines = false;   // spt_tribvh.h
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
@@ -222,6 +222,7 @@ void spt_destroy(spt_ctx* c)
     if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
     if (c->d_bvh_cones) (void)hipFree(c->d_bvh_cones);
     if (c->d_cam_planes) (void)hipFree(c->d_cam_planes);
+    if (c->d_flat_line_index) (void)hipFree(c->d_flat_line_index);
     if (c->d_flat_lines) (void)hipFree(c->d_flat_lines);
     if (c->d_plane_nodes) (void)hipFree(c->d_plane_nodes);
     if (c->d_line_nodes) (void)hipFree(c->d_line_nodes);
@@ -656,8 +657,11 @@ static int build_accel(spt_ctx* c)
     c->have_planes = !bvh.planes.empty(); c->have_lines = !bvh.lines.empty();
     if (c->have_planes) SPT_HIP(c, upload(c->d_plane_nodes, bvh.planes.data(), bvh.planes.size() * sizeof(float4)));
     if (c->have_lines) SPT_HIP(c, upload(c->d_line_nodes, bvh.lines.data(), bvh.lines.size() * sizeof(float4)));
-    c->bvh_flat = bvh.flat && bvh.thin_count; c->nthin = bvh.thin_count; c->cam_valid = false;
-    if (c->bvh_flat) SPT_HIP(c, upload(c->d_flat_lines, bvh.flat_lines.data(), bvh.flat_lines.size() * sizeof(float4)));
+    c->bvh_flat = bvh.flat && bvh.thin_count; c->nline_slots = (uint32_t)bvh.flat_lines.size(); c->cam_valid = false;
+    if (c->bvh_flat) {
+        SPT_HIP(c, upload(c->d_flat_lines, bvh.flat_lines.data(), bvh.flat_lines.size() * sizeof(float4)));
+        SPT_HIP(c, upload(c->d_flat_line_index, bvh.flat_line_index.data(), bvh.flat_line_index.size() * sizeof(uint32_t)));
+    }
     SPT_HIP(c, upload(c->d_bvh_cones, bvh.cones.data(), bvh.cones.size() * sizeof(float4)));
     c->bvh_nodes = (uint32_t)(bvh.nodes.size() / 4); c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.leaves;
     c->bvh_ready = true;
@@ -721,7 +725,7 @@ static spt::MParams mesh_params(const spt_ctx* c)
             M.bvh_cones = c->d_bvh_cones;
             if (c->have_planes) M.plane_nodes = c->d_plane_nodes;
             if (c->have_lines) M.line_nodes = c->d_line_nodes;
-            if (c->bvh_flat) { M.flat_lines = c->d_flat_lines; M.nthin = c->nthin; }
+            if (c->bvh_flat) { M.flat_lines = c->d_flat_lines; M.flat_line_index = c->d_flat_line_index; M.nline_slots = c->nline_slots; }
         }
     }
     return M;

@@ -505,12 +505,70 @@ void build_bvh(const float4* recs, uint32_t ntris, Bvh& out, int form)
     planes.run();
     out.flat = form == 1 || (form == 0 && out.thin_count <= kTriFlatLines);     // the thin triangles as a table or as a tree (spt_tribvh.h (3))
     if (out.flat) {
-        for (const ConeItem& it : lines.items) {
-            float4 v = make_float4((float)it.v0[0], (float)it.v0[1], (float)it.v0[2], 0.f);
-            std::memcpy(&v.w, &it.gid, 4);
-            out.flat_lines.push_back(make_float4((float)it.d[0], (float)it.d[1], (float)it.d[2], round_up(it.tol * (1.0 + 1e-6))));
-            out.flat_lines.push_back(v);
+        // groups of lines through a common point: the long edge's two endpoints of every thin triangle are hashed on a grid of 2^-18 of the
+        // scene's size; the fullest cell takes every triangle that has an endpoint in it (a pole takes its needles), and so on; what
+        // shares no endpoint with three others stands alone (p = v0)
+        const double cell = std::max(planes.dir_scale, 1e-30) * 0x1p-18;
+        struct End { long long k[3]; uint32_t item; double p[3]; };
+        std::vector<End> ends;
+        const uint32_t nt = (uint32_t)lines.items.size();
+        std::vector<double> elen(nt);
+        for (uint32_t i = 0; i < nt; ++i) {
+            const TriGeom t = tri_geom(recs + 3 * (size_t)lines.items[i].gid);
+            elen[i] = std::max(t.l1, t.l2);
+            for (int side = 0; side < 2; ++side) {
+                End e{};
+                e.item = i;
+                for (int a = 0; a < 3; ++a) { e.p[a] = lines.items[i].v0[a] + (side ? lines.items[i].d[a] * elen[i] : 0.0); e.k[a] = (long long)std::floor(e.p[a] / cell); }
+                ends.push_back(e);
+            }
         }
+        // (the direction of an item may have been flipped nowhere yet: cone_item keeps eL's own orientation, so v0 + d |eL| is the far end)
+        std::sort(ends.begin(), ends.end(), [](const End& x, const End& y) {
+            for (int a = 0; a < 3; ++a) if (x.k[a] != y.k[a]) return x.k[a] < y.k[a];
+            return x.item < y.item;
+        });
+        struct Cell { size_t lo, hi; };
+        std::vector<Cell> cells;
+        for (size_t i = 0; i < ends.size();) {
+            size_t j = i + 1;
+            while (j < ends.size() && ends[j].k[0] == ends[i].k[0] && ends[j].k[1] == ends[i].k[1] && ends[j].k[2] == ends[i].k[2]) ++j;
+            cells.push_back({i, j});
+            i = j;
+        }
+        std::sort(cells.begin(), cells.end(), [](const Cell& x, const Cell& y) { return x.hi - x.lo > y.hi - y.lo || (x.hi - x.lo == y.hi - y.lo && x.lo < y.lo); });
+        std::vector<char> taken(nt, 0);
+        auto emit_group = [&](const std::vector<uint32_t>& members, const double p[3]) {
+            float4 h = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+            const uint32_t cnt = (uint32_t)members.size();
+            std::memcpy(&h.w, &cnt, 4);
+            out.flat_lines.push_back(h);
+            out.flat_line_index.push_back(0xFFFFFFFFu);
+            for (uint32_t i : members) {
+                const ConeItem& it = lines.items[i];
+                const double rel[3] = {it.v0[0] - h.x, it.v0[1] - h.y, it.v0[2] - h.z};
+                double cr[3];
+                cross3(it.d, rel, cr);
+                const double tol = std::sqrt(dot3(cr, cr)) + it.tol + 8.1 * 0x1p-24 * std::sqrt(dot3(rel, rel));
+                out.flat_lines.push_back(make_float4((float)it.d[0], (float)it.d[1], (float)it.d[2], round_up(tol * (1.0 + 1e-6) + 1e-30)));
+                out.flat_line_index.push_back(it.gid);
+            }
+        };
+        for (const Cell& c : cells) {
+            std::vector<uint32_t> members;
+            double p[3] = {0, 0, 0};
+            for (size_t i = c.lo; i < c.hi; ++i)
+                if (!taken[ends[i].item] && (members.empty() || members.back() != ends[i].item)) {
+                    members.push_back(ends[i].item);
+                    for (int a = 0; a < 3; ++a) p[a] += ends[i].p[a];
+                }
+            if (members.size() < 4) continue;
+            for (int a = 0; a < 3; ++a) p[a] /= (double)members.size();
+            for (uint32_t i : members) taken[i] = 1;
+            emit_group(members, p);
+        }
+        for (uint32_t i = 0; i < nt; ++i)
+            if (!taken[i]) emit_group(std::vector<uint32_t>{i}, lines.items[i].v0);
     } else {
         lines.run();
     }
@@ -755,20 +813,31 @@ bool validate_bvh(const float4* recs, uint32_t ntris, const Bvh& bvh, std::strin
     }
     if (bvh.regular_count != nreg || bvh.thin_count != nthin || bvh.dead_count != ndead) { why = "triangle class counts"; return false; }
     if (!validate_walk(recs, 3, ntris, regular, pb, bvh, why)) return false;
-    if (bvh.flat) {                                                          // the thin triangles as a table
-        if (!bvh.lines.empty() || bvh.flat_lines.size() != 2 * (size_t)nthin) { why = "line table size"; return false; }
+    if (bvh.flat) {                                                          // the thin triangles as a table of groups
+        if (!bvh.lines.empty() || bvh.flat_lines.size() != bvh.flat_line_index.size()) { why = "line table size"; return false; }
         std::vector<uint32_t> seen(ntris, 0u);
-        for (uint32_t k = 0; k < nthin; ++k) {
-            const float4 e = bvh.flat_lines[2 * (size_t)k], v = bvh.flat_lines[2 * (size_t)k + 1];
-            uint32_t g;
-            std::memcpy(&g, &v.w, 4);
-            if (g >= ntris || !thin[g] || seen[g]++) { why = "line table index"; return false; }
-            double dd = 0.0;
-            for (int a = 0; a < 3; ++a) { const double d = (&e.x)[a] - item[g].d[a]; dd += d * d; }
-            if (!(std::sqrt(dd) <= 3e-7 && (double)e.w >= item[g].tol && v.x == (float)item[g].v0[0] && v.y == (float)item[g].v0[1] && v.z == (float)item[g].v0[2])) {
-                why = "line table record " + std::to_string(g); return false;
+        uint32_t listed = 0;
+        for (size_t i = 0; i < bvh.flat_lines.size();) {
+            const float4 h = bvh.flat_lines[i];
+            uint32_t cnt;
+            std::memcpy(&cnt, &h.w, 4);
+            if (cnt == 0 || i + cnt > bvh.flat_lines.size() - 1) { why = "line table group header"; return false; }
+            for (uint32_t k = 1; k <= cnt; ++k) {
+                const float4 e = bvh.flat_lines[i + k];
+                const uint32_t g = bvh.flat_line_index[i + k];
+                if (g >= ntris || !thin[g] || seen[g]++) { why = "line table index"; return false; }
+                double dd = 0.0;
+                for (int a = 0; a < 3; ++a) { const double d = (&e.x)[a] - item[g].d[a]; dd += d * d; }
+                const double rel[3] = {item[g].v0[0] - h.x, item[g].v0[1] - h.y, item[g].v0[2] - h.z};
+                double cr[3];
+                cross3(item[g].d, rel, cr);
+                const double need = std::sqrt(dot3(cr, cr)) + item[g].tol + 8.1 * 0x1p-24 * std::sqrt(dot3(rel, rel));
+                if (!(std::sqrt(dd) <= 3e-7 && (double)e.w >= need)) { why = "line table record " + std::to_string(g); return false; }
+                ++listed;
             }
+            i += (size_t)cnt + 1;
         }
+        if (listed != nthin) { why = "line table: thin triangles listed " + std::to_string(listed) + " of " + std::to_string(nthin); return false; }
     } else if (!bvh.flat_lines.empty()) { why = "line table beside the line tree"; return false; }
     if (!validate_cones(bvh, geo, why)) return false;
     if (!validate_cone_tree(bvh.planes, true, item, regular, why)) { why = "plane tree: " + why; return false; }

@@ -42,8 +42,10 @@ struct Bvh {
     // triangle ~r (record 3 * ~r of the scene's table).  Triangles with an edge of length zero are in no structure (never accepted,
     // spt_tribvh.h (0)).
     std::vector<float4> planes, lines;
-    // up to kTriFlatLines thin triangles are kept as a table instead of `lines` (spt_tribvh.h (3)): {eh, a} {v0, global index} each
+    // up to kTriFlatLines thin triangles are kept as a table instead of `lines` (spt_tribvh.h (3)): groups {p, count} {eh, tol} ...;
+    // flat_line_index[slot] = the record's global triangle
     std::vector<float4> flat_lines;
+    std::vector<uint32_t> flat_line_index;
     std::vector<float4> cones;        // spatial tree, 3 float4 per node: {left axis, kappa} {right axis, kappa} {left 1/g_max, left 1.016 e_max, right ..} (spt_tribvh.h (1))
     uint32_t regular_count = 0, thin_count = 0, dead_count = 0, ball_depth = 0;
     bool flat = false;                // the thin triangles are a table (flat_lines), not a tree (lines)

@@ -64,8 +64,9 @@ struct MParams {
     const float4* bvh_cones;       // 3 per node of the hierarchy: the children's normal cones (spt_tribvh.h (1)); null = SPT_ACCEL_BVH_FAST
     const float4* plane_nodes;     // cone tree over the regular triangles' planes (spt_tribvh.h (2)); null = none
     const float4* line_nodes;      // cone tree over the thin triangles' long edges (spt_tribvh.h (3)); null = none or the table below
-    const float4* flat_lines;      // table form of the thin triangles: {eh, a} {v0, index} each; null = none or the tree above
-    uint32_t nthin;
+    const float4* flat_lines;      // table form of the thin triangles: groups {p, count} {eh, tol} ... (spt_tribvh.h); null = none or the tree above
+    const uint32_t* flat_line_index;
+    uint32_t nline_slots;
     // rays of depth 0 of a render launch (their lines all pass through the camera's origin) skip the plane tree and test this list instead:
     // the regular triangles in whose plane that origin lies (spt_bvh.h camera_planes; empty, as a rule).  cam_cull = 0: spt_trace_rays
     const uint32_t* cam_planes;

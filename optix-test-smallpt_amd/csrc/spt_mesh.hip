@@ -153,12 +153,16 @@ __device__ __forceinline__ uint32_t closest_triangle_few(const float4* __restric
 // triangle's plane, or near the supporting line of a thin triangle's long edge -- find those triangles through two ball trees in
 // plane space and line space.  The walks and node tests are the host / device functions of spt_tribvh.h, which the CPU harness
 // (tests/sanitize/tribvh_main.cpp) runs against the exhaustive loop.
+constexpr uint32_t kMeshArgOffset = (uint32_t)((sizeof(KParams) + alignof(MParams) - 1) / alignof(MParams) * alignof(MParams));   // meshkernel(KParams, MParams)
 struct LdsStack {
     uint32_t* base;                                            // entry e of thread t at base[e * kMeshBlock + t]: conflict-free
     __device__ __forceinline__ void push(uint32_t sp, uint32_t v) { base[sp * kMeshBlock + threadIdx.x] = v; }
     __device__ __forceinline__ uint32_t pop(uint32_t sp) const { return base[sp * kMeshBlock + threadIdx.x]; }
 };
 
+// KOFF = byte offset of the MParams argument in the kernel-argument segment: what only the plane / line structures need is read from
+// there where it is used (scalar loads) instead of sitting in SGPRs through the whole bounce loop (cf. the camera constants of meshkernel).
+template <uint32_t KOFF>
 __device__ __forceinline__ uint32_t closest_triangle_bvh(const MParams& M, uint32_t* s_stack, bool active, bool camera_ray, f3 ro, f3 rd, float& t_out)
 {
     uint32_t near_key = kMeshInfKey, near_tri = 0xFFFFFFFFu;
@@ -184,13 +188,18 @@ __device__ __forceinline__ uint32_t closest_triangle_bvh(const MParams& M, uint3
             tri_walk_boxes<false>(M.bvh_nodes, nullptr, ro.x, ro.y, ro.z, ivx, ivy, ivz, q.h[0], q.h[1], q.h[2], tcut, st, leaf);
         } else {
             tri_walk_boxes<true>(M.bvh_nodes, M.bvh_cones, ro.x, ro.y, ro.z, ivx, ivy, ivz, q.h[0], q.h[1], q.h[2], tcut, st, leaf);
-            if (camera_ray) {                                      // one origin for the whole frame: the planes through it are listed (spt_bvh.h camera_planes)
-                for (uint32_t k = 0; k < M.ncam; ++k) by_index(M.cam_planes[k]);
-            } else if (M.plane_nodes) {
-                tri_walk_planes(M.plane_nodes, q, st, by_index);
+            typedef const __attribute__((address_space(4))) MParams* MArgs;
+            MArgs mc = (MArgs)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
+            asm volatile("" : "+s"(mc));
+            if (camera_ray) {                                      // the planes through the camera point are listed (spt_bvh.h camera_planes)
+                const uint32_t ncam = mc->ncam;
+                const uint32_t* cam_planes = mc->cam_planes;
+                for (uint32_t k = 0; k < ncam; ++k) by_index(cam_planes[k]);
+            } else if (mc->plane_nodes) {
+                tri_walk_planes(mc->plane_nodes, q, st, by_index);
             }
-            if (M.flat_lines) tri_scan_lines(M.flat_lines, M.nthin, q, st, by_index);
-            else if (M.line_nodes) tri_walk_lines(M.line_nodes, q, st, by_index);
+            if (mc->flat_lines) tri_scan_lines(mc->flat_lines, mc->flat_line_index, mc->nline_slots, q, st, by_index);
+            else if (mc->line_nodes) tri_walk_lines(mc->line_nodes, q, st, by_index);
         }
     }
     t_out = __uint_as_float(near_key + 1u);
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(kMeshBlock) void trace_rays(const MParams M, const 
     f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (active) { ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]); rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]); }
     float t;
-    const uint32_t tri = BVH ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), active, false, ro, rd, t)
+    const uint32_t tri = BVH ? closest_triangle_bvh<0u>(M, reinterpret_cast<uint32_t*>(s_tile), active, false, ro, rd, t)
                              : closest_triangle(M.tris, M.ntris, s_tile, active, ro, rd, t);
     if (!active) return;
     float* h = hits + 11 * i;
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
         }
         // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
         const uint32_t tri = GEOM == 2 ? (coop ? coop_tri : closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t))
-                           : GEOM == 1 ? closest_triangle_bvh(M, reinterpret_cast<uint32_t*>(s_tile), alive, M.cam_cull != 0u && p.depth == 0u, p.o, p.d, t)
+                           : GEOM == 1 ? closest_triangle_bvh<kMeshArgOffset>(M, reinterpret_cast<uint32_t*>(s_tile), alive, M.cam_cull != 0u && p.depth == 0u, p.o, p.d, t)
                            : nalive <= (uint32_t)kFewRays ? closest_triangle_few(M.tris, M.ntris, s_tile, nalive, alive, p.o, p.d, t)
                                        : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
         if (alive) {

@@ -268,9 +268,8 @@ SPT_THD void tri_walk_lines(const float4* __restrict__ nodes, const TriQuery& q,
 
 // ---- (3), table form.  A per-lane tree walk on a GPU is a chain of dependent, scattered loads; a loop over a table that every lane of a
 // wave reads at the same index is not: read through the constant address space it is a scalar load (s_load_dwordx8 into SGPRs) and the
-// test a dozen VALU instructions with SGPR operands.  Up to kTriFlatLines thin triangles are therefore kept as a table of 32-byte
-// records {eh, a} {v0, global index} and every ray scans it: a record is listed when |eh.((v0 - ro) x rdh)| <= a + 32 u |v0 - ro| (the
-// exact condition of (3) for one line), the listed triangles are tested.  (The same form was tried for the PLANES of small scenes --
+// test a few VALU instructions with SGPR operands.  Up to kTriFlatLines thin triangles are therefore kept as a table that every ray
+// scans (layout and test below); the listed triangles are tested.  (The same form was tried for the PLANES of small scenes --
 // one {nh, c0 g} per triangle, c0 = 2^-9, boxes inflated by 2^-8 D: a ray lists 0.3 % of the triangles, a wave of 64 unrelated rays
 // a fifth of them, and testing the listed ones cost more than the whole exhaustive loop: 33 ms against 29 ms for a 1280 x 720 frame
 // of the shipped 8192-triangle scene.  Not kept: profiles/r04_triangle_hierarchy.txt.)
@@ -279,27 +278,34 @@ typedef const __attribute__((address_space(4))) float4 tri_flat_t;
 #else
 typedef const float4 tri_flat_t;
 #endif
-SPT_THD bool tri_flat_line_pass(const float4 e, const float4 v, const TriQuery& q)
-{
-    const float dx = v.x - q.o[0], dy = v.y - q.o[1], dz = v.z - q.o[2];
-    const float mx = dy * q.h[2] - dz * q.h[1], my = dz * q.h[0] - dx * q.h[2], mz = dx * q.h[1] - dy * q.h[0];
-    const float am = e.x * mx + e.y * my + e.z * mz;
-    const float d = tri_sqrt(dx * dx + dy * dy + dz * dz);
-    return __builtin_fabsf(am) <= e.w + 0x1p-19f * d;
-}
-
-// cand(g): test global triangle g.  The list is the per-ray stack, drained when full.
+// The table is a sequence of GROUPS: a header {p, number of records} followed by that many records {eh, tol}; p is a point all the
+// group's lines pass (nearly) through -- the pole, for the needles of a pole: their long edges all end there --, tol = dist(p, line) + a +
+// 8.1 u |v0 - p|.  Per group the ray's moment about p, m = (p - ro) x rdh, is formed once, a record then costs a dot product:
+// |eh.m| <= tol + 32 u |p - ro|   ((3) with a cone of one direction).  index[slot] = the record's global triangle.
 template <class Stack, class Cand>
-SPT_THD void tri_scan_lines(const float4* __restrict__ flat_, uint32_t nthin, const TriQuery& q, Stack& st, Cand&& cand)
+SPT_THD void tri_scan_lines(const float4* __restrict__ flat_, const uint32_t* __restrict__ index_, uint32_t nslots, const TriQuery& q, Stack& st, Cand&& cand)
 {
     tri_flat_t* flat = (tri_flat_t*)flat_;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) uint32_t* index = (const __attribute__((address_space(4))) uint32_t*)index_;
+#else
+    const uint32_t* index = index_;
+#endif
     uint32_t sp = 0;
-    for (uint32_t i = 0; i < nthin; ++i) {
-        const float4 e = flat[2 * (size_t)i], v = flat[2 * (size_t)i + 1];
-        if (tri_flat_line_pass(e, v, q)) {
-            st.push(sp, __builtin_bit_cast(uint32_t, v.w));
-            if (++sp == 32u) { while (sp) { --sp; cand(st.pop(sp)); } }
+    for (uint32_t i = 0; i < nslots;) {
+        const float4 h = flat[i];
+        const uint32_t cnt = __builtin_bit_cast(uint32_t, h.w);
+        const float dx = h.x - q.o[0], dy = h.y - q.o[1], dz = h.z - q.o[2];
+        const float mx = dy * q.h[2] - dz * q.h[1], my = dz * q.h[0] - dx * q.h[2], mz = dx * q.h[1] - dy * q.h[0];
+        const float thr = 0x1p-19f * tri_sqrt(dx * dx + dy * dy + dz * dz);
+        for (uint32_t k = 1; k <= cnt; ++k) {
+            const float4 e = flat[i + k];
+            if (__builtin_fabsf(e.x * mx + e.y * my + e.z * mz) <= e.w + thr) {
+                st.push(sp, index[i + k]);
+                if (++sp == 32u) { while (sp) { --sp; cand(st.pop(sp)); } }
+            }
         }
+        i += cnt + 1u;
     }
     while (sp) { --sp; cand(st.pop(sp)); }
 }

@@ -118,7 +118,7 @@ void closest_bvh(const Scene& s, const spt::Bvh& bvh, V3 ro, V3 rd, uint32_t& ne
         else if (!bvh.planes.empty()) spt::tri_walk_planes(bvh.planes.data(), q, st, plane);
     }
     if (!no_lines) {
-        if (bvh.flat) { if (bvh.thin_count) spt::tri_scan_lines(bvh.flat_lines.data(), bvh.thin_count, q, st, line); }
+        if (bvh.flat) { if (bvh.thin_count) spt::tri_scan_lines(bvh.flat_lines.data(), bvh.flat_line_index.data(), (uint32_t)bvh.flat_lines.size(), q, st, line); }
         else if (!bvh.lines.empty()) spt::tri_walk_lines(bvh.lines.data(), q, st, line);
     }
     cost.box_nodes += visited;
