@@ -63,7 +63,7 @@ inline uint32_t levels_needed(uint32_t count, uint32_t leaf_max)
 struct Builder {
     const float4* recs;              // rec_f4 float4 per primitive, indexed by GLOBAL id
     uint32_t rec_f4 = 3;
-    uint32_t leaf_max = kBvhLeafTris; // primitives per leaf (<= 7: three bits of the leaf reference)
+    uint32_t leaf_max = kBvhLeafTris; // primitives per leaf (<= 15: four bits of the leaf reference)
     std::vector<uint32_t> ids;       // global id of every primitive handed to the builder (empty = identity)
     std::vector<Box> box;            // per primitive
     std::vector<float> cen;          // 3 per primitive
@@ -120,14 +120,14 @@ struct Builder {
             for (uint32_t k = 0; k < rec_f4; ++k) out->tris.push_back(recs[rec_f4 * (size_t)g + k]);
         }
         ++out->leaves;
-        return ~(int32_t)((first << 3) | (hi - lo));
+        return ~(int32_t)((first << 4) | (hi - lo));
     }
 
     // whole hierarchy over the primitives whose boxes / centroids are set; the root is always node 0
     void run()
     {
         const uint32_t n = (uint32_t)box.size();
-        if (n >= (1u << 28)) throw std::runtime_error("hierarchy: too many primitives for the leaf encoding");
+        if (n >= (1u << 27)) throw std::runtime_error("hierarchy: too many primitives for the leaf encoding");
         order.resize(n);
         std::iota(order.begin(), order.end(), 0u);
         out->index.reserve(n); out->tris.reserve(rec_f4 * (size_t)n);
@@ -629,7 +629,7 @@ void build_sphere_bvh(const float4* geom, const float* radius, uint32_t n, Bvh& 
     }
     out.always = huge;
     Builder b;
-    b.recs = geom; b.rec_f4 = 1; b.out = &out;
+    b.recs = geom; b.rec_f4 = 1; b.out = &out; b.leaf_max = kBvhLeafSpheres;
     size_t h = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (h < huge.size() && huge[h] == i) { ++h; continue; }
@@ -656,8 +656,8 @@ static bool validate_walk(const float4* recs, uint32_t rec_f4, uint32_t ntris, c
     while (!stack.empty()) {
         const Item it = stack.back(); stack.pop_back();
         if (it.ref < 0) {
-            const uint32_t code = (uint32_t)~it.ref, first = code >> 3, cnt = code & 7u;
-            if (cnt > 7u) { why = "leaf count"; return false; }
+            const uint32_t code = (uint32_t)~it.ref, first = code >> 4, cnt = code & 15u;
+            if (cnt > 15u) { why = "leaf count"; return false; }
             if (it.depth > kBvhMaxDepth) { why = "leaf deeper than the bound"; return false; }
             for (uint32_t k = 0; k < cnt; ++k) {
                 if (first + k >= bvh.index.size()) { why = "leaf range"; return false; }
@@ -769,7 +769,7 @@ static bool validate_cones(const Bvh& bvh, const std::vector<TriGeom>& geo, std:
     while (!stack.empty()) {
         const Item it = stack.back(); stack.pop_back();
         if (it.ref < 0) {
-            const uint32_t code = (uint32_t)~it.ref, first = code >> 3, cnt = code & 7u;
+            const uint32_t code = (uint32_t)~it.ref, first = code >> 4, cnt = code & 15u;
             for (uint32_t k = 0; k < cnt; ++k) {
                 const TriGeom& t = geo[bvh.index[first + k]];
                 const double nh[3] = {t.n[0] / t.nn, t.n[1] / t.nn, t.n[2] / t.nn};

@@ -22,13 +22,18 @@
 #include <string>
 #include <vector>
 
+#ifndef SPT_BVH_LEAF_TRIS
+#define SPT_BVH_LEAF_TRIS 12
+#endif
+
 namespace spt {
 
 constexpr uint32_t kBvhMaxDepth = 32;      // children of the root are at depth 1; a leaf reference sits at depth <= 32
-constexpr uint32_t kBvhLeafTris = 4;         // primitives per leaf (triangles or spheres)
+constexpr uint32_t kBvhLeafTris = SPT_BVH_LEAF_TRIS;   // triangles per leaf (measured on the shipped scene: 2 / 4 / 7 per leaf = 28.7 / 23.3 / 19.1 ms at 256^2 x 256 spp)
+constexpr uint32_t kBvhLeafSpheres = 4;      // spheres per leaf (round 2: 2 ... 7 within 3 %)
 constexpr uint32_t kBvhAlways = 32;          // sphere hierarchies: at most this many outsized spheres are tested for every ray
 
-// Child reference: >= 0 = node index; < 0 = leaf, ~ref = (first leaf-order triangle << 3) | count (count 0 = empty).
+// Child reference: >= 0 = node index; < 0 = leaf, ~ref = (first leaf-order triangle << 4) | count (count 0 = empty).
 struct Bvh {
     std::vector<float4> nodes;        // 4 x float4 per node: {lmin.xyz, lmax.x} {lmax.yz, rmin.xy} {rmin.z, rmax.xyz} {left, right, 0, 0}
     std::vector<float4> tris;         // 3 x float4 per triangle in leaf order (the records of MParams::tris)

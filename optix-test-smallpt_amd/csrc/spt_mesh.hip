@@ -285,7 +285,7 @@ __device__ __forceinline__ uint32_t closest_sphere_bvh(const KParams& K, const M
                 }
                 if (hl | hr) { cur = hl ? lref : rref; continue; }
             } else {
-                const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = code & 7u;
+                const uint32_t code = (uint32_t)~cur, first = code >> 4, cnt = code & 15u;
                 for (uint32_t k = 0; k < cnt; ++k) consider(leaf_geom[first + k], leaf_index[first + k]);
             }
             if (sp == 0u) break;

@@ -214,7 +214,7 @@ SPT_THD void tri_walk_boxes(const float4* __restrict__ nodes, const float4* __re
             if (hl | hr) { cur = hl ? lref : rref; continue; }
         } else {
             const uint32_t code = (uint32_t)~cur;
-            leaf(code >> 3, code & 7u);
+            leaf(code >> 4, code & 15u);
         }
         if (sp == 0u) break;
         --sp;

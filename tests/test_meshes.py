@@ -189,7 +189,7 @@ def _soup(pkg, n, seed, flat=False):
 
 
 def test_bvh_builder_structure(pkg):
-    """Host-side invariants of the hierarchy (no GPU): every triangle in exactly one leaf of <= 4, every box contains the
+    """Host-side invariants of the hierarchy (no GPU): every triangle in exactly one leaf of <= 12, every box contains the
     padded triangles below it, no reference deeper than the traversal's 32-entry stack; degenerate inputs included."""
     S = pkg.make_sphere_trimesh
     tri = pkg.single_triangle_scene()[0][0]
@@ -211,8 +211,8 @@ def test_bvh_builder_structure(pkg):
         else:
             needles = {"shipped": 2 * 2 * 64, "mixed sizes": 2 * 48 + 2 * 16}.get(name, 0)
             assert needles // 2 <= total - ntris <= needles, (name, total - ntris)
-        if ntris > 4:
-            assert leaves >= (ntris + 3) // 4 and nodes == leaves - 1, (name, nodes, leaves)
+        if ntris > 12:                                       # leaves of <= 12 triangles (kBvhLeafTris)
+            assert leaves >= (ntris + 11) // 12 and nodes == leaves - 1, (name, nodes, leaves)
     rc, _, why = _selftest_bvh(pkg, [pkg.TriMesh(np.array([[0, 0, 0], [1, 0, 0], [np.inf, 1, 0]], dtype=np.float32), tri.normals, tri.indices)])
     assert rc == 1 and "non-finite" in why
 
