@@ -153,6 +153,7 @@ __device__ __forceinline__ uint32_t closest_triangle_few(const float4* __restric
 // triangle's plane, or near the supporting line of a thin triangle's long edge -- find those triangles through two ball trees in
 // plane space and line space.  The walks and node tests are the host / device functions of spt_tribvh.h, which the CPU harness
 // (tests/sanitize/tribvh_main.cpp) runs against the exhaustive loop.
+constexpr uint32_t kCoopTriangleRays = 49152;                   // meshkernel<1>: a wave with few live rays answers them with the exhaustive loop
 constexpr uint32_t kMeshArgOffset = (uint32_t)((sizeof(KParams) + alignof(MParams) - 1) / alignof(MParams) * alignof(MParams));   // meshkernel(KParams, MParams)
 struct LdsStack {
     uint32_t* base;                                            // entry e of thread t at base[e * kMeshBlock + t]: conflict-free
@@ -483,9 +484,49 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
                 }
             }
         }
+        // ---- triangle hierarchy, the same situation (a lone mirror / glass chain keeps one lane of a wave busy for thousands of bounces, each a
+        // chain of dependent node loads: the Cornell-like mesh scene of tests/test_meshes.py took 745 ms through the hierarchy against
+        // 116 ms through the exhaustive loop before this): the wave answers each of its <= 4 rays with the exhaustive loop of
+        // scene.cpp:95-116 -- lane l tests triangles l, l + 64, ... (ascending, strict '<'), then the lexicographic minimum of (key,
+        // index) over the wave -- which is the answer by definition.  Taken while (live rays) x (triangles) <= kCoopTriangleRays, i.e. at most
+        // 768 tests per lane: about what a wave's pass through the hierarchy costs whatever the number of its live lanes. ----
+        if (GEOM == 1) {
+            unsigned long long todo = __ballot(alive);
+            coop = todo != 0ull && (uint32_t)__popcll(todo) * M.ntris <= kCoopTriangleRays;
+            if (coop) {
+                while (todo != 0ull) {
+                    const int rl = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const f3 ro = mk(__shfl(p.o.x, rl), __shfl(p.o.y, rl), __shfl(p.o.z, rl)), rd = mk(__shfl(p.d.x, rl), __shfl(p.d.y, rl), __shfl(p.d.z, rl));
+                    uint32_t wk = kMeshInfKey, wi = 0xFFFFFFFFu;
+                    auto test = [&](const float4 r0, const float4 r1, const float4 r2, uint32_t i) {
+                        float u, v;
+                        const float tt = tri_test(r0, r1, r2, ro, rd, u, v);
+                        const uint32_t key = __float_as_uint(tt) - 1u;
+                        const bool better = key < wk;                                   // ascending i per lane: strict '<' keeps the lowest index
+                        wk = better ? key : wk; wi = better ? i : wi;
+                    };
+                    uint32_t i = lane;
+                    for (; i + 192u < M.ntris; i += 256u) {                             // four records per lane in flight per round trip (a chain of bounces is latency)
+                        const float4* r = M.tris + 3 * (size_t)i;
+                        const float4 a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[192], b1 = r[193], b2 = r[194];
+                        const float4 c0 = r[384], c1 = r[385], c2 = r[386], d0 = r[576], d1 = r[577], d2 = r[578];
+                        test(a0, a1, a2, i); test(b0, b1, b2, i + 64u); test(c0, c1, c2, i + 128u); test(d0, d1, d2, i + 192u);
+                    }
+                    for (; i < M.ntris; i += 64u) test(M.tris[3 * (size_t)i], M.tris[3 * (size_t)i + 1], M.tris[3 * (size_t)i + 2], i);
+#pragma unroll 1
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const uint32_t k2 = (uint32_t)__shfl_xor((int)wk, off), i2 = (uint32_t)__shfl_xor((int)wi, off);
+                        const bool better = (k2 < wk) | ((k2 == wk) & (i2 < wi));
+                        wk = better ? k2 : wk; wi = better ? i2 : wi;
+                    }
+                    if ((int)lane == rl) { coop_tri = wk < kMeshInfKey ? wi : 0xFFFFFFFFu; t = __uint_as_float(wk + 1u); }
+                }
+            }
+        }
         // ---- closest hit over all triangles (whole workgroup; idle lanes only help staging) ----
         const uint32_t tri = GEOM == 2 ? (coop ? coop_tri : closest_sphere_bvh(K, M, M.bvh_nodes, M.bvh_tris, M.bvh_index, reinterpret_cast<uint32_t*>(s_tile), alive, p.o, p.d, t))
-                           : GEOM == 1 ? closest_triangle_bvh<kMeshArgOffset>(M, reinterpret_cast<uint32_t*>(s_tile), alive, M.cam_cull != 0u && p.depth == 0u, p.o, p.d, t)
+                           : GEOM == 1 ? (coop ? coop_tri : closest_triangle_bvh<kMeshArgOffset>(M, reinterpret_cast<uint32_t*>(s_tile), alive, M.cam_cull != 0u && p.depth == 0u, p.o, p.d, t))
                            : nalive <= (uint32_t)kFewRays ? closest_triangle_few(M.tris, M.ntris, s_tile, nalive, alive, p.o, p.d, t)
                                        : closest_triangle(M.tris, M.ntris, s_tile, alive, p.o, p.d, t);
         if (alive) {
