@@ -143,12 +143,12 @@ int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const 
  *     differences on 700 000 random and adversarial rays, the CPU harness tests/sanitize/tribvh_main.cpp runs the same walk
  *     functions against the exhaustive loop.  A render launch lists the triangles in whose plane the camera's origin lies once
  *     (the lines of all its rays of depth 0 pass through that point) and those rays test the list instead of walking the plane
- *     tree.  Cost, shipped scene (8192 triangles), 1280 x 720 x 4 spp: 3.4 ms per pinhole frame, 4.4 ms with the smallpt camera,
+ *     tree.  Cost, shipped scene (8192 triangles), 1280 x 720 x 4 spp: 1.4 ms per pinhole frame, 1.5 ms with the smallpt camera,
  *     against 25-29 ms through the exhaustive loop; spt_trace_rays_device 0.41 Grays/s against 0.125.  A ray that starts hundreds of scene sizes away degrades
  *     towards the exhaustive loop's cost (the error bound grows with the distance), never in result.
  *   SPT_ACCEL_EXHAUSTIVE: every triangle of every instance is tested, as CPUIntersector::intersect does (smallpt.cpp:443-458 over
  *     scene.cpp:95-116): the parity anchor.
- *   SPT_ACCEL_BVH_FAST (opt-in): the bounding-volume hierarchy alone, as in rounds 2-3 -- 2.2 ms for the pinhole frame above.  It
+ *   SPT_ACCEL_BVH_FAST (opt-in): the bounding-volume hierarchy alone, as in rounds 2-3 -- 1.05 ms for the pinhole frame above.  It
  *     returns the exhaustive Hit whenever the winning triangle's padded box is crossed within the current nearest distance; a ray
  *     lying (to ~1e-7 rad) in a triangle's plane, or crossing a needle's supporting line, may lose the noise "hit" the reference's
  *     arithmetic reports there.  Rendered images have never met the condition (tests compare them), constructed rays do.

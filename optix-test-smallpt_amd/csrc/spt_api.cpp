@@ -56,6 +56,7 @@ struct spt_ctx {
     int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy, 4 grid kernel (lanes own paths), 5 grid kernel with path pools
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
+    bool mesh_specular = false;            // a mesh material is SPEC or REFR: long mirror / glass chains are possible (task dealing of the hierarchy kernel)
     float4* d_tris = nullptr; uint4* d_tri_index = nullptr; float4* d_verts = nullptr; uint32_t* d_inst_first = nullptr; float4* d_mesh_mats = nullptr;
     float* d_trace_rays = nullptr; float* d_trace_hits = nullptr; uint64_t trace_cap = 0;   // spt_trace_rays staging (rays)
     std::vector<float4> h_geom;      // host copy of the sphere table {centre, r*r} and the radii: its hierarchy is built on demand
@@ -596,6 +597,7 @@ static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, c
     std::vector<uint4> tidx((size_t)(ntris ? ntris : 1));
     std::vector<uint32_t> first((size_t)nmesh + 1, 0u);
     size_t t = 0, vbase = 0;
+    bool specular = false;
     for (uint32_t i = 0; i < nmesh; ++i) {
         const spt_mesh& m = meshes[i];
         first[i] = (uint32_t)t;
@@ -615,6 +617,7 @@ static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, c
         }
         vbase += m.nverts;
         material_rows(materials[i].emission, materials[i].color, materials[i].refl, &mats[3 * (size_t)i]);
+        specular = specular || materials[i].refl != SPT_DIFF;
     }
     first[nmesh] = (uint32_t)t;
     auto upload = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
@@ -631,6 +634,7 @@ static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, c
     SPT_HIP(c, upload(c->d_mesh_mats, mats.data(), mats.size() * sizeof(float4)));
     c->ntris = (uint32_t)ntris; c->ninst = nmesh;
     c->mesh_scene = true;
+    c->mesh_specular = specular;
     tris.resize(3 * (size_t)ntris);
     c->h_tris.swap(tris);
     c->bvh_ready = false;
@@ -719,6 +723,7 @@ static spt::MParams mesh_params(const spt_ctx* c)
     spt::MParams M{};
     M.tris = c->d_tris; M.tri_index = c->d_tri_index; M.verts = c->d_verts; M.inst_first_tri = c->d_inst_first; M.mats = c->d_mesh_mats;
     M.ntris = c->ntris; M.ninst = c->ninst;
+    M.strips = c->mesh_specular ? 0u : 1u;
     if (c->accel != SPT_ACCEL_EXHAUSTIVE && c->bvh_ready) {
         M.bvh_nodes = c->d_bvh_nodes; M.bvh_tris = c->d_bvh_tris; M.bvh_index = c->d_bvh_index;
         if (c->accel == SPT_ACCEL_BVH) {                           // (SPT_ACCEL_BVH_FAST: the spatial tree alone, no cones)

@@ -24,4 +24,22 @@ SPT_DEAL_HD uint32_t deal_task(uint32_t q, uint32_t ntasks)
     return ((q >> 6) < nch && t < ntasks) ? t : 0xFFFFFFFFu;
 }
 
+// ---- the triangle hierarchy's kernel deals the other way round in one respect (scenes without mirror / glass materials): the 64 tasks
+// of a chunk belong to an 8 x 8 TILE of pixels -- their rays visit the same nodes, the per-lane walks of a wave have similar lengths and
+// the node loads hit the cache (the shipped mesh scene at 1280 x 720: 4.4 -> 1.5 ms per frame; 64 x 1 strips: 1.7) -- while the S = 4 * NB
+// tasks of ONE pixel still lie far apart in the queue: chunk c stands for (sub, tile) = (c / G, c % G), G = ceil(w / 8) * ceil(rows / 8)
+// (w x rows pixels, row-major, pixel ids as in the task id), and its lane l for the tile's pixel (l & 7, l >> 3), task (y w + x) S + sub.
+// Positions of a tile's part beyond the image are holes (0xFFFFFFFF) INSIDE the range -- the caller fetches again --; everything at or
+// beyond deal_tiles_end() is the end.
+SPT_DEAL_HD uint32_t deal_tiles_end(uint32_t w, uint32_t rows, uint32_t S) { return ((w + 7u) >> 3) * ((rows + 7u) >> 3) * 64u * S; }
+SPT_DEAL_HD uint32_t deal_task_tiles(uint32_t q, uint32_t w, uint32_t rows, uint32_t S)
+{
+    const uint32_t gx = (w + 7u) >> 3, G = gx * ((rows + 7u) >> 3);
+    const uint32_t c = q >> 6, l = q & 63u;
+    const uint32_t sub = c / G, g = c - sub * G;
+    const uint32_t ty = g / gx, tx = g - ty * gx;
+    const uint32_t x = (tx << 3) + (l & 7u), y = (ty << 3) + (l >> 3);
+    return (sub < S && x < w && y < rows) ? (y * w + x) * S + sub : 0xFFFFFFFFu;
+}
+
 #endif

@@ -71,6 +71,10 @@ struct MParams {
     // the regular triangles in whose plane that origin lies (spt_bvh.h camera_planes; empty, as a rule).  cam_cull = 0: spt_trace_rays
     const uint32_t* cam_planes;
     uint32_t ncam, cam_cull;
+    // hierarchy kernel: 1 = the lanes of a wave are dealt an 8 x 8 tile of pixels (spt_deal.h deal_task_tiles: coherent walks, 2.5 x on diffuse
+    // scenes); 0 = a pixel's tasks and its neighbours' go to different waves (deal_task), chosen when a material is SPEC or REFR: a tile of
+    // pixels looking into a mirror or glass ball would put 64 chains of thousands of bounces into one wave
+    uint32_t strips;
     // sphere tables through the same kernel (spt_set_sphere_accel): bvh_tris holds one {centre, r*r} per sphere in leaf order,
     // `always` the spheres kept out of the tree; hits take centre / material from KParams::geom / mat
     const uint32_t* always;

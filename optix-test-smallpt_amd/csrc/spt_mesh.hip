@@ -383,8 +383,16 @@ __global__ __launch_bounds__(kMeshBlock) void meshkernel(const KParams K, const 
         }
         if (!alive && s_gen == s_end && !queue_empty) {
             if (task_valid) K.cells[task] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-            const uint32_t qpos = atomicAdd(K.queue, 1u);     // the triangle loop dwarfs this atomic
-            task = deal_task(qpos, K.ntasks);                 // (spt_device.h: a pixel's blocks go to different waves)
+            uint32_t qpos = atomicAdd(K.queue, 1u);           // the triangle loop dwarfs this atomic
+            if (GEOM == 1 && M.strips) {
+                // through the triangle hierarchy the lanes of a wave hold an 8 x 8 TILE of pixels (spt_deal.h deal_task_tiles; scenes without
+                // mirror / glass materials, MParams::strips); a tile's part beyond the image is a hole inside the range: fetch again
+                const uint32_t S = 4u << K.nb_log2, rows = K.ntasks / (S * K.w), qend = deal_tiles_end(K.w, rows, S);
+                task = deal_task_tiles(qpos, K.w, rows, S);
+                while (task == 0xFFFFFFFFu && qpos < qend) { qpos = atomicAdd(K.queue, 1u); task = deal_task_tiles(qpos, K.w, rows, S); }
+            } else {
+                task = deal_task(qpos, K.ntasks);             // (spt_deal.h: a pixel's blocks go to different waves)
+            }
             task_valid = task < K.ntasks;
             if (task_valid) {
                 const uint32_t cellid = task >> K.nb_log2, blk = task & ((1u << K.nb_log2) - 1u);

@@ -120,7 +120,8 @@ def test_task_dealing_is_a_bijection(tmp_path):
     """csrc/spt_deal.h deal_task (which task a queue position stands for in the grid-pool, grid, mega and mesh kernels): every task id exactly
     once over the valid positions, "no task" for the holes of the last stride, for positions at or beyond the end and for the grid-pool
     kernel's nothing-left position -- the property whose violation (a sentinel inside the valid range) made a launch loop for ever
-    once during round 4 (tests/sanitize/deal_main.cpp, under ASan + UBSan)."""
+    once during round 4 --, and deal_task_tiles (the triangle hierarchy's kernel: a chunk = an 8 x 8 tile of pixels with one sub-index): every task
+    exactly once below deal_tiles_end(), holes only for a tile's part beyond the image (tests/sanitize/deal_main.cpp, under ASan + UBSan)."""
     exe = tmp_path / "deal_main"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            os.path.join(ROOT, "tests", "sanitize", "deal_main.cpp"), "-o", str(exe)])
