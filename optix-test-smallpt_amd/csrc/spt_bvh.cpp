@@ -238,7 +238,7 @@ struct Builder {
 
 }  // namespace
 
-// ---- triangle classes and the two ball trees of spt_tribvh.h ---------------------------------------------------------------
+// ---- triangle classes, the cone trees and the line table of spt_tribvh.h ---------------------------------------------------------------
 namespace {
 
 enum TriClass { kTriDead = 0, kTriRegular = 1, kTriThin = 2 };

@@ -9,9 +9,9 @@
 // the triangles it visits and selects by the same rule (smallest t > 0, lowest (instance, triangle) index among equal
 // t), so it returns the exhaustive loop's hit whenever it visits that triangle -- and since round 4 it provably visits
 // every triangle whose reported key beats or ties the answer (spt_tribvh.h): this spatial hierarchy finds the reports
-// whose error is bounded (its child boxes are inflated per ray), a ball tree over the triangles' PLANES finds the rays
+// whose error is bounded (its child boxes are inflated per ray), a cone tree over the triangles' PLANES finds the rays
 // that lie in a regular triangle's plane to rounding (triIntersect has no determinant cut-off, scene.cpp:62, and reports
-// noise there), a ball tree over the long edges' LINES finds the thin triangles (needles, zero area) whatever the ray.
+// noise there), a table (or cone tree) of the long edges' LINES finds the thin triangles (needles, zero area) whatever the ray.
 #ifndef SPT_BVH_H
 #define SPT_BVH_H
 #include <hip/hip_runtime.h>

@@ -15,9 +15,10 @@
 //     shading decisions (D1-D19) as the sphere kernels; hit.n is the interpolated, un-normalised vertex normal exactly
 //     as makeHit returns it.  This is the reference's actual direction of travel (OptiX triangles); the exhaustive loop is
 //     the default and the correctness anchor.
-//   * SPT_ACCEL_BVH (opt-in, spt_bvh.h): the same query by a per-lane stack traversal of a padded binary hierarchy -- same
-//     triIntersect arithmetic on the visited triangles, same selection rule (smallest t > 0, lowest global index among
-//     equal t) -- the stand-in for the OptiX Prime traversal of smallpt.cpp:475-603.
+//   * SPT_ACCEL_BVH (the default of mesh scenes since round 4; spt_bvh.h, spt_tribvh.h): the same query through structures that provably reach
+//     every triangle whose report beats or ties the answer -- same triIntersect arithmetic on the triangles they reach, same selection rule
+//     (smallest t > 0, lowest global index among equal t) --: the stand-in for the OptiX Prime traversal of smallpt.cpp:475-603, and the
+//     exhaustive loop's Hit for every ray.  SPT_ACCEL_BVH_FAST: the spatial hierarchy alone.
 #include "spt_device.h"
 #include "spt_kernel.h"
 
@@ -150,8 +151,8 @@ __device__ __forceinline__ uint32_t closest_triangle_few(const float4* __restric
 // key is smaller, or equal with a lower global index: the (instance, triangle)-ascending strict '<' of the reference's loops.
 // Since round 4 the query is exhaustive-equivalent for every ray (spt_tribvh.h): the spatial walk inflates the child boxes per ray and
 // finds every report whose error is bounded; the rays for which triIntersect's determinant is zero to rounding -- in a regular
-// triangle's plane, or near the supporting line of a thin triangle's long edge -- find those triangles through two ball trees in
-// plane space and line space.  The walks and node tests are the host / device functions of spt_tribvh.h, which the CPU harness
+// triangle's plane, or near the supporting line of a thin triangle's long edge -- find those triangles through a cone tree over the
+// triangles' planes and a table (or tree) of the long edges' lines.  The walks and node tests are the host / device functions of spt_tribvh.h, which the CPU harness
 // (tests/sanitize/tribvh_main.cpp) runs against the exhaustive loop.
 constexpr uint32_t kCoopTriangleRays = 49152;                   // meshkernel<1>: a wave with few live rays answers them with the exhaustive loop
 constexpr uint32_t kMeshArgOffset = (uint32_t)((sizeof(KParams) + alignof(MParams) - 1) / alignof(MParams) * alignof(MParams));   // meshkernel(KParams, MParams)
