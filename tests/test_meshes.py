@@ -381,6 +381,41 @@ def test_bvh_fast_mode_agrees_on_ordinary_rays(pkg, renderer):
 
 
 @pytest.mark.gpu
+def test_mesh_scenes_of_degenerate_triangles_only(pkg):
+    """Scenes in which one of the hierarchy's structures (or all of them) is empty: only triangles with an edge of length zero (in no
+    structure), only needles (the line table alone), one of each, a single regular triangle -- every mode returns the exhaustive loop's
+    hits and image, nothing is read out of bounds."""
+    def mesh(tris):
+        v = np.asarray(tris, dtype=np.float32).reshape(-1, 3)
+        return pkg.TriMesh(v, np.tile(np.array([0, 1, 0], dtype=np.float32), (len(v), 1)), np.arange(len(v), dtype=np.uint32).reshape(-1, 3))
+    cases = {"only zero-edge triangles": [[[0, 0, 0], [0, 0, 0], [1, 0, 0]], [[1, 1, 1], [1, 1, 1], [2, 2, 2]]],
+             "only needles": [[[0, 0, 0], [5, 0, 1e-7], [5, 0, 0]], [[0, 1, 0], [5, 1, 0], [5, 1, 2e-7]], [[0, 0, -3], [4, 0, -3], [2, 0, -3]]],
+             "a zero-edge triangle and a regular one": [[[0, 0, 0], [0, 0, 0], [1, 0, 0]], [[-1, -1, -3], [1, -1, -3], [0, 1, -3]]],
+             "one regular triangle": [[[-1, -1, -3], [1, -1, -3], [0, 1, -3]]]}
+    rs = np.random.RandomState(0)
+    o = rs.uniform(-2, 2, (20000, 3)); d = rs.normal(size=(20000, 3))
+    rays = [np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1)]
+    p = np.stack([rs.uniform(-10, 10, 2000), rs.choice([0.0, 1.0], 2000), rs.choice([0.0, 1e-7, -3.0], 2000)], axis=1)     # along the needles' lines, in their planes
+    dd = np.stack([rs.choice([-1.0, 1.0], 2000), np.zeros(2000), rs.uniform(-1e-7, 1e-7, 2000)], axis=1)
+    rays.append(np.concatenate([p, dd / np.linalg.norm(dd, axis=1, keepdims=True)], axis=1))
+    rays = np.concatenate(rays).astype(np.float32)
+    with pkg.Renderer(0) as r:
+        for name, tris in cases.items():
+            meshes = [mesh(tris)]
+            mats = [((0, 0, 0), (.5, .5, .5), pkg.DIFF)]
+            out = {}
+            for accel in (pkg.ACCEL_EXHAUSTIVE, pkg.ACCEL_BVH, pkg.ACCEL_BVH_FAST):
+                r.set_mesh_accel(accel)
+                r.set_meshes(meshes, mats)
+                out[accel] = (r.trace_rays(rays), r.render(32, 24, 1, seed=1, camera=pkg.pinhole_camera())[0])
+            ref = out[pkg.ACCEL_EXHAUSTIVE]
+            assert np.array_equal(out[pkg.ACCEL_BVH][0].view(np.uint8), ref[0].view(np.uint8)) and np.array_equal(out[pkg.ACCEL_BVH][1], ref[1]), name
+            assert np.array_equal(out[pkg.ACCEL_BVH_FAST][1], ref[1]), name
+            if "regular" in name:
+                assert (ref[0]["dist"] < 1e20).sum() > 100, name
+
+
+@pytest.mark.gpu
 def test_bvh_render_equals_exhaustive_and_oracle(pkg, renderer, oracle):
     """The mesh path tracer through the hierarchy: same image, same bounce count as the exhaustive kernel and the oracle."""
     meshes, mats = _mesh_scene(pkg)
