@@ -32,9 +32,11 @@
 //     longest edge e_max below it.  Every triangle inside has |nh.rdh| >= c := |a.rdh| - kappa, i.e. M >= c / (u g_max) when that is
 //     >= M0; otherwise its triangles either have M >= M0 or belong to (2).  With D = distance from ro to the box's farthest corner
 //     (R <= D) the child box is inflated by
-//       pad = 32.5 u (D + 1.016 e_max) / max(c / g_max, tau0) * 1.03
-//     -- 2e-6 D for a patch facing the ray, 1.6 % of D for one seen edge-on or one whose normals spread widely (the upper levels).
-//     The 3 % cover the slab arithmetic (3 u D), the 1-ulp v_rcp / v_sqrt and the rounding of a.rdh (3 u against tau0 = 2^-13).
+//       pad = 37 u (D + 1.016 e_max) / max(c / g_max, tau0) * 1.03
+//     -- 2e-6 D for a patch facing the ray, 1.8 % of D for one seen edge-on or one whose normals spread widely (the upper levels).
+//     37 = 32.5 + 4.5: the slab test itself (differences, products with the 1-ulp v_rcp of rd) misplaces a face by up to 3 u D, which
+//     must not eat into the bound where the pad is at its smallest (c = 1); the 3 % cover the 1-ulp v_sqrt in D and the rounding of
+//     a.rdh (3 u against tau0 = 2^-13).  Coordinates and edges are assumed to stay clear of underflow and overflow (1e-15 ... 1e15).
 //     P_c is in every inflated ancestor box at the parameter t_c <= the current nearest: the triangle is reached.
 //
 // (2) REGULAR triangles, rays with |rd.n*| < M0 u |rd| E (the direction lies in the plane to within tau = kTriBand g; M = M0 below).  Acceptance
@@ -86,7 +88,7 @@ namespace spt {
 constexpr double kTriBand = 1.0 / 8192.0;         // tau0 = M0 u, M0 = 2^11: (1) / (2) split at |nh.rdh| = kTriBand * g
 constexpr double kTriThinG = 32.0;                // g above which a triangle is THIN (3)
 constexpr uint32_t kTriFlatLines = 16384;         // up to this many thin triangles are scanned as a table instead of walked as a tree (3)
-constexpr float kTriPadK = 32.5f * 0x1p-24f * 1.03f;   // (1): pad = kTriPadK (D + e') / max((|a.rdh| - kappa) / g_max, tau0), e' = 1.016 e_max
+constexpr float kTriPadK = 37.0f * 0x1p-24f * 1.03f;   // (1): pad = kTriPadK (D + e') / max((|a.rdh| - kappa) / g_max, tau0), e' = 1.016 e_max; 37 = 32.5 + 4.5 for the slab arithmetic
 
 // Per ray (closest-hit query): origin and unit direction (a NaN / inf / zero direction makes every comparison below false: nothing is
 // visited, and the exhaustive loop reports nothing either -- det = NaN or 0 gives t = NaN or inf).
