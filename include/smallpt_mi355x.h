@@ -128,8 +128,11 @@ typedef struct spt_hit { float dist; uint32_t instId; uint32_t triId; float x[3]
  * un-normalised vertex normal).  spt_set_scene switches back to spheres. */
 int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const spt_material* materials);
 
-/* How the closest hit of a mesh scene is found.  SPT_ACCEL_BVH and SPT_ACCEL_EXHAUSTIVE return the same Hit for EVERY ray (since round 4).
- *   SPT_ACCEL_BVH (default since round 4): the role of the OptiX Prime model/query of the reference's GPU intersector
+/* How the closest hit of a mesh scene is found.  SPT_ACCEL_BVH and SPT_ACCEL_EXHAUSTIVE return the same Hit for EVERY ray (since round 4),
+ * and the default, SPT_ACCEL_AUTO, picks between these two per launch: the hierarchy, unless the scene has fewer than 256 triangles or --
+ * renders only -- fewer than 8192 and more than 15 % of its last launch's closest-hit queries were bounce rays (those walk the plane tree
+ * below; under that size the exhaustive loop is then the faster of the two).  Results never depend on the choice.
+ *   SPT_ACCEL_BVH: the role of the OptiX Prime model/query of the reference's GPU intersector
  *     (smallpt.cpp:475-603, the intersector the reference actually runs, :605): structures built over the triangles when the
  *     meshes are set.  The triangles they reach go through the same triIntersect arithmetic and the same selection (smallest
  *     dist > 0, lowest (instance, triangle) among equal dist) as the exhaustive loop, and they provably reach every triangle whose
@@ -156,6 +159,7 @@ int  spt_set_meshes(spt_ctx* ctx, const spt_mesh* meshes, uint32_t nmesh, const 
 #define SPT_ACCEL_EXHAUSTIVE 0
 #define SPT_ACCEL_BVH        1
 #define SPT_ACCEL_BVH_FAST   3   /* mesh scenes only: the spatial hierarchy alone (rounds 2-3), see above */
+#define SPT_ACCEL_AUTO       4   /* mesh scenes only, the default: SPT_ACCEL_BVH or SPT_ACCEL_EXHAUSTIVE, whichever is expected to be faster */
 int  spt_set_mesh_accel(spt_ctx* ctx, int accel);
 /* How the closest hit of a SPHERE table larger than the 24 the material-sorted kernel unrolls is found (smallpt.cpp:54-70 loops
  * over all of them).  Every mode returns the exhaustive loop's hit for every ray -- same intersectAnalytic arithmetic

@@ -53,7 +53,7 @@ struct spt_ctx {
     float* d_stack = nullptr;      // pool kernel: global-memory stack of pending transmitted children
     size_t stack_cap = 0;          // in floats
     bool last_was_pool = false;
-    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles), 3 mesh kernel over a sphere hierarchy, 4 grid kernel (lanes own paths), 5 grid kernel with path pools
+    int last_kernel = 0;           // 0 megakernel, 1 pool kernel, 2 mesh kernel (triangles; 6 / 7: through the exact / the plain hierarchy), 3 mesh kernel over a sphere hierarchy, 4 grid kernel (lanes own paths), 5 grid kernel with path pools
     // triangle-mesh scene (spt_set_meshes); mesh_scene selects it for spt_render*
     bool mesh_scene = false;
     bool mesh_specular = false;            // a mesh material is SPEC or REFR: long mirror / glass chains are possible (task dealing of the hierarchy kernel)
@@ -72,7 +72,9 @@ struct spt_ctx {
     float4* d_sbvh_nodes = nullptr; float4* d_sbvh_geom = nullptr; uint32_t* d_sbvh_index = nullptr; uint32_t* d_sbvh_always = nullptr;
     uint32_t sbvh_nalways = 0, sbvh_depth = 0;
     std::vector<float4> h_tris;      // host copy of the triangle records: the hierarchy is built from it on demand
-    int accel = SPT_ACCEL_BVH;             // mesh scenes (spt_set_mesh_accel): exhaustive-equivalent for every ray since round 4 (spt_tribvh.h)
+    int accel = SPT_ACCEL_AUTO;            // mesh scenes (spt_set_mesh_accel): one of the two modes that return the exhaustive loop's Hit for every ray (spt_tribvh.h)
+    float mesh_ratio = -1.f;               // closest-hit queries per sample of the last synchronised launch of this mesh scene (-1: none yet): SPT_ACCEL_AUTO
+    int last_mesh_mode = SPT_ACCEL_EXHAUSTIVE;   // what the last mesh launch / query ran through
     bool bvh_ready = false;          // the hierarchy below belongs to the current mesh scene
     float4* d_bvh_nodes = nullptr; float4* d_bvh_tris = nullptr; uint32_t* d_bvh_index = nullptr;
     float4* d_flat_lines = nullptr; uint32_t* d_flat_line_index = nullptr; uint32_t nline_slots = 0; bool bvh_flat = false;     // thin triangles as a table (spt_tribvh.h (3))
@@ -635,6 +637,7 @@ static int set_meshes_impl(spt_ctx* c, const spt_mesh* meshes, uint32_t nmesh, c
     c->ntris = (uint32_t)ntris; c->ninst = nmesh;
     c->mesh_scene = true;
     c->mesh_specular = specular;
+    c->mesh_ratio = -1.f;
     tris.resize(3 * (size_t)ntris);
     c->h_tris.swap(tris);
     c->bvh_ready = false;
@@ -675,7 +678,7 @@ static int build_accel(spt_ctx* c)
 int spt_set_mesh_accel(spt_ctx* c, int accel)
 {
     if (!c) return 1;
-    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH && accel != SPT_ACCEL_BVH_FAST) return c->fail("spt_set_mesh_accel: unknown mode %d", accel);
+    if (accel != SPT_ACCEL_EXHAUSTIVE && accel != SPT_ACCEL_BVH && accel != SPT_ACCEL_BVH_FAST && accel != SPT_ACCEL_AUTO) return c->fail("spt_set_mesh_accel: unknown mode %d", accel);
     c->accel = accel;
     if (accel == SPT_ACCEL_EXHAUSTIVE || !c->mesh_scene || c->bvh_ready) return 0;
     try {
@@ -718,15 +721,27 @@ int spt_selftest_bvh(const spt_mesh* meshes, uint32_t nmesh, uint32_t* out4, cha
     }
 }
 
-static spt::MParams mesh_params(const spt_ctx* c)
+// Which closest-hit mode a launch (render = true) or a ray query of the current mesh scene takes.  SPT_ACCEL_AUTO picks between the two EXACT
+// modes: the hierarchy, unless the scene is tiny (< 256 triangles) or -- for renders -- small (< 8192 triangles) and, in its last launch, more than
+// 15 % of the closest-hit queries were bounce rays: those walk the plane tree (only camera rays have their list), and below that size the
+// exhaustive loop is then the faster exact mode (profiles/r04_triangle_hierarchy.txt, size sweep).
+static int mesh_mode(const spt_ctx* c, bool render)
+{
+    if (c->accel != SPT_ACCEL_AUTO) return c->bvh_ready || c->accel == SPT_ACCEL_EXHAUSTIVE ? c->accel : SPT_ACCEL_EXHAUSTIVE;
+    if (!c->bvh_ready || c->ntris < 256u) return SPT_ACCEL_EXHAUSTIVE;
+    if (render && c->ntris < 8192u && c->mesh_ratio > 1.15f) return SPT_ACCEL_EXHAUSTIVE;
+    return SPT_ACCEL_BVH;
+}
+
+static spt::MParams mesh_params(const spt_ctx* c, int mode)
 {
     spt::MParams M{};
     M.tris = c->d_tris; M.tri_index = c->d_tri_index; M.verts = c->d_verts; M.inst_first_tri = c->d_inst_first; M.mats = c->d_mesh_mats;
     M.ntris = c->ntris; M.ninst = c->ninst;
     M.strips = c->mesh_specular ? 0u : 1u;
-    if (c->accel != SPT_ACCEL_EXHAUSTIVE && c->bvh_ready) {
+    if (mode != SPT_ACCEL_EXHAUSTIVE && c->bvh_ready) {
         M.bvh_nodes = c->d_bvh_nodes; M.bvh_tris = c->d_bvh_tris; M.bvh_index = c->d_bvh_index;
-        if (c->accel == SPT_ACCEL_BVH) {                           // (SPT_ACCEL_BVH_FAST: the spatial tree alone, no cones)
+        if (mode == SPT_ACCEL_BVH) {                           // (SPT_ACCEL_BVH_FAST: the spatial tree alone, no cones)
             M.bvh_cones = c->d_bvh_cones;
             if (c->have_planes) M.plane_nodes = c->d_plane_nodes;
             if (c->have_lines) M.line_nodes = c->d_line_nodes;
@@ -744,7 +759,8 @@ int spt_trace_rays_device(spt_ctx* c, const void* d_rays, uint64_t n, void* d_hi
     if (!d_rays || !d_hits) return c->fail("spt_trace_rays_device: NULL argument");
     if (n > 0x7FFFFFFFull * 256ull) return c->fail("spt_trace_rays_device: too many rays for one call");
     SPT_HIP(c, hipSetDevice(c->device));
-    const spt::MParams M = mesh_params(c);
+    c->last_mesh_mode = mesh_mode(c, false);
+    const spt::MParams M = mesh_params(c, c->last_mesh_mode);
     SPT_HIP(c, spt_mesh_trace_rays(&M, static_cast<const float*>(d_rays), n, static_cast<float*>(d_hits),
                                    hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream));
     return 0;
@@ -772,7 +788,8 @@ int spt_trace_rays(spt_ctx* c, const spt_ray* rays, uint64_t n, spt_hit* hits)
     }
     float* const d_rays = c->d_trace_rays;
     float* const d_hits = c->d_trace_hits;
-    const spt::MParams M = mesh_params(c);
+    c->last_mesh_mode = mesh_mode(c, false);
+    const spt::MParams M = mesh_params(c, c->last_mesh_mode);
     // 24 B per ray up and 44 B per hit down through the caller's pageable buffers: the host link is the bound (measured 176 Mrays/s
     // for 1 Mi rays against 1.3 Grays/s of the kernel on the shipped scene's hierarchy; chunks on two streams were tried and are
     // slower, pageable copies do not overlap).  spt_trace_rays_device skips the link.
@@ -988,7 +1005,9 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
     if (c->mesh_scene || sphere_bvh) {
         // (a short launch -- the viewer's frames -- takes three workgroups per CU instead of four: 661 -> 672 frames/s on the shipped scene
         // through the hierarchy at 1280x720 x 4 spp, 949 -> 1033 with two frames in flight, which then share the CUs; tools/ab_mesh_viewer_blocks.py)
-        const bool through_hierarchy = sphere_bvh || (c->mesh_scene && c->accel != SPT_ACCEL_EXHAUSTIVE && c->bvh_ready);   // (the exhaustive tile loop keeps four)
+        const int mode = c->mesh_scene ? mesh_mode(c, true) : SPT_ACCEL_EXHAUSTIVE;
+        if (c->mesh_scene) c->last_mesh_mode = mode;
+        const bool through_hierarchy = sphere_bvh || (c->mesh_scene && mode != SPT_ACCEL_EXHAUSTIVE);   // (the exhaustive tile loop keeps four)
         const uint32_t mesh_per_cu = c->blocks_per_cu ? c->blocks_per_cu : (through_hierarchy && npix * 4ull * samps < (4ull << 20) ? 3u : 4u);
         uint64_t blocks = (uint64_t)c->cu_count * mesh_per_cu;
         const uint64_t needed = (ntasks + 255) / 256;
@@ -1008,7 +1027,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
             M.always = c->d_sbvh_always; M.nalways = c->sbvh_nalways; M.sphere_mode = 1u;
         } else {
             P.n = 0; P.n_pad = 1; P.geom = nullptr; P.mat = nullptr;
-            M = mesh_params(c);
+            M = mesh_params(c, mode);
             if (M.plane_nodes) {
                 // every ray of depth 0 lies on a line through cam->origin and starts at most |push| |d| from it (push = 0: a pinhole
                 // camera, every ray starts there), and a ray can only be reported by a regular triangle through a determinant that is
@@ -1043,7 +1062,7 @@ static int render_rows_impl(spt_ctx* c, const spt_camera* cam, uint32_t w, uint3
         SPT_HIP(c, hipEventRecord(c->ev_stop, st));
         c->pending = true;
         c->last_was_pool = false;
-        c->last_kernel = sphere_bvh ? 3 : 2;
+        c->last_kernel = sphere_bvh ? 3 : (mode == SPT_ACCEL_BVH ? 6 : (mode == SPT_ACCEL_BVH_FAST ? 7 : 2));
         c->last = spt_stats{};
         c->last.samples = npix * 4ull * samps;
         c->last.grid_blocks = (uint32_t)blocks;
@@ -1212,6 +1231,8 @@ int spt_sync(spt_ctx* c, spt_stats* stats)
         c->last.kernel_ms = ms;
         c->last.bounces = ctr[0];
         c->last.max_depth_kills = ctr[1];
+        if (c->mesh_scene && (c->last_kernel == 2 || c->last_kernel == 6 || c->last_kernel == 7) && c->last.samples)
+            c->mesh_ratio = (float)((double)c->last.bounces / (double)c->last.samples);
         if (c->variant & 0x100u) SPT_HIP(c, hipMemcpy(c->diag, c->d_counters + 2, sizeof c->diag, hipMemcpyDeviceToHost));
         c->pending = false;
         if (c->last_was_pool || c->last_kernel == 4 || c->last_kernel == 5) {

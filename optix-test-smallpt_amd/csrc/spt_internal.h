@@ -39,7 +39,7 @@ int  spt_diag(spt_ctx* ctx, unsigned long long* out24);
  * cannot hang the GPU box. */
 int  spt_set_watchdog(spt_ctx* ctx, double seconds);
 /* Which kernel ran the last launch: 1 = material-sorted pool kernel (spt_pool.hip), 0 = megakernel (spt_kernel.hip),
- * 2 = mesh kernel (spt_mesh.hip, triangles), 3 = mesh kernel over a sphere hierarchy (SPT_ACCEL_BVH), 4 = grid kernel with lane-owned
+ * 2 = mesh kernel (spt_mesh.hip, triangles, exhaustive loop; 6 = through the exact hierarchy, 7 = through the plain one), 3 = mesh kernel over a sphere hierarchy (SPT_ACCEL_BVH), 4 = grid kernel with lane-owned
  * paths (spt_grid.hip), 5 = grid kernel with wave-private path pools (spt_gpool.hip).
  * After a grid launch spt_diag returns out24[0..1] = cell steps / sphere tests of the walks, [2..3] = wave iterations of either kind,
  * [4] = rays that took the exhaustive loop, [5] = rounds, [7] = shaded hits.

@@ -14,7 +14,7 @@ from .scene import HIT_DTYPE, RAY_DTYPE, SPHERE_DTYPE
 
 FLAG_NORMALISE = 1
 FLAG_ONE_SHOT = 2          # scheduling only: no dispatch order used or recorded for this launch (include/smallpt_mi355x.h)
-ACCEL_EXHAUSTIVE, ACCEL_BVH, ACCEL_GRID, ACCEL_BVH_FAST = 0, 1, 2, 3
+ACCEL_EXHAUSTIVE, ACCEL_BVH, ACCEL_GRID, ACCEL_BVH_FAST, ACCEL_AUTO = 0, 1, 2, 3, 4
 
 
 class SptError(RuntimeError):
@@ -143,8 +143,8 @@ class Renderer:
         self._state_version += 1
 
     def set_mesh_accel(self, accel):
-        """ACCEL_BVH (default since round 4: the role of the reference's OptiX Prime model, smallpt.cpp:475-603; the exhaustive loop's
-        Hit for every ray, include/smallpt_mi355x.h), ACCEL_EXHAUSTIVE (every triangle, the reference's CPU loops: the parity anchor) or
+        """ACCEL_AUTO (default: the faster of the two exact modes per launch), ACCEL_BVH (the role of the reference's OptiX Prime model,
+        smallpt.cpp:475-603; the exhaustive loop's Hit for every ray, include/smallpt_mi355x.h), ACCEL_EXHAUSTIVE (every triangle, the reference's CPU loops: the parity anchor) or
         ACCEL_BVH_FAST (the plain hierarchy of rounds 2-3: several times faster, but rays lying in a triangle's plane to rounding may differ)."""
         self._check(self._lib.spt_set_mesh_accel(self._h, int(accel)))
         self._state["mesh_accel"] = int(accel)
@@ -223,7 +223,7 @@ class Renderer:
         """'pool' (spt_pool.hip, material-sorted), 'mega' (spt_kernel.hip), 'mesh' (spt_mesh.hip, triangles), 'sbvh' (spt_mesh.hip over a
         sphere hierarchy), 'gpool' (spt_gpool.hip, uniform grid over a large sphere table driven by wave-private path pools: the default above 24
         spheres) or 'grid' (spt_grid.hip, the same grid with lanes that own their path: tables that leave no LDS for the pools) for the last launch."""
-        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh", 4: "grid", 5: "gpool"}[self._lib.spt_last_kernel(self._h)]
+        return {0: "mega", 1: "pool", 2: "mesh", 3: "sbvh", 4: "grid", 5: "gpool", 6: "mesh_bvh", 7: "mesh_bvh_fast"}[self._lib.spt_last_kernel(self._h)]
 
     def render_interleaved_device(self, out_tensor, w, h, block_rows, world, rank, samps_per_cell, seed=0,
                                   normalise=False, camera=None, stream=None):

@@ -324,9 +324,8 @@ def test_bvh_trace_rays_equals_exhaustive(pkg, renderer):
 
 
 @pytest.mark.gpu
-def test_default_mode_is_the_exact_hierarchy_and_pinhole_frames_list_the_origins_planes(pkg, oracle):
-    """A fresh context renders a mesh scene through SPT_ACCEL_BVH (the default since round 4) -- same image, same bounce count as the
-    exhaustive kernel and the oracle, with both cameras.  For a pinhole camera the rays of depth 0 skip the plane tree and test the
+def test_exact_hierarchy_renders_and_camera_rays_list_the_camera_points_planes(pkg, oracle):
+    """A mesh scene through SPT_ACCEL_BVH -- same image, same bounce count as the exhaustive kernel and the oracle, with both cameras.  For a pinhole camera the rays of depth 0 skip the plane tree and test the
     triangles in whose plane the camera's origin lies (spt_bvh.h camera_planes) instead: checked with the origin IN the plane of the
     scene's single triangle, looking along that plane (a non-empty list) and at main()'s position (an empty one)."""
     meshes, mats = _mesh_scene(pkg)
@@ -340,10 +339,12 @@ def test_default_mode_is_the_exact_hierarchy_and_pinhole_frames_list_the_origins
     cams = [None, pkg.pinhole_camera(), pkg.pinhole_camera(vx=tuple(vx), vz=tuple(vz), org=tuple(org)), pkg.pinhole_camera(org=tuple(org))]
     w, h, samps, seed = 40, 30, 2, 5
     with pkg.Renderer(0) as r:
-        r.set_meshes(meshes, mats)                           # no set_mesh_accel: the default
+        r.set_mesh_accel(pkg.ACCEL_BVH)
+        r.set_meshes(meshes, mats)
         imgs = []
         for cam in cams:
             img, st = r.render(w, h, samps, seed=seed, normalise=cam is None, camera=cam)
+            assert r.last_kernel() == "mesh_bvh"
             imgs.append((img, st["bounces"]))
         r.set_mesh_accel(pkg.ACCEL_EXHAUSTIVE)
         for cam, (img, bounces) in zip(cams, imgs):
@@ -352,6 +353,37 @@ def test_default_mode_is_the_exact_hierarchy_and_pinhole_frames_list_the_origins
         for cam, (img, bounces) in zip(cams[:2], imgs[:2]):
             ref, rst = oracle.render_meshes(meshes, mats, w, h, samps, seed=seed, normalise=cam is None, camera=cam)
             assert np.array_equal(img, ref) and bounces == rst["bounces"]
+
+
+@pytest.mark.gpu
+def test_default_mode_picks_between_the_two_exact_modes(pkg, oracle):
+    """SPT_ACCEL_AUTO, the default: a fresh context renders a mesh scene through the exact hierarchy; once a launch of a small scene
+    (< 8192 triangles) has shown that more than 15 % of its closest-hit queries are bounce rays (they walk the plane tree) the next launch
+    takes the exhaustive loop; a scene that is mostly camera rays, or large, stays on the hierarchy; fewer than 256 triangles always take
+    the loop.  The image never depends on the choice."""
+    S = pkg.make_sphere_trimesh
+    meshes, mats = _mesh_scene(pkg)                          # 3329 triangles, 1.3-1.4 closest-hit queries per sample
+    ref, rst = oracle.render_meshes(meshes, mats, 40, 30, 2, seed=5)
+    with pkg.Renderer(0) as r:
+        r.set_meshes(meshes, mats)                           # no set_mesh_accel: the default
+        kernels = []
+        for _ in range(3):
+            img, st = r.render(40, 30, 2, seed=5)
+            kernels.append(r.last_kernel())
+            assert np.array_equal(img, ref) and st["bounces"] == rst["bounces"]
+        assert kernels == ["mesh_bvh", "mesh", "mesh"], kernels
+        shipped = [S((50, 40.8, 81.6), 10.0), S((50, 681.6 - .27, 81.6), 600.0)]            # 8192 triangles: the hierarchy whatever the bounce share
+        r.set_meshes(shipped, [((0, 0, 0), (.75, .25, .25), pkg.DIFF), ((1, 1, 1), (0, 0, 0), pkg.DIFF)])
+        for _ in range(2):
+            r.render(64, 48, 1, seed=1)
+            assert r.last_kernel() == "mesh_bvh"
+        tiny, tmats = pkg.single_triangle_scene()
+        r.set_meshes(tiny, tmats)
+        r.render(64, 48, 1, seed=1, camera=pkg.pinhole_camera())
+        assert r.last_kernel() == "mesh"
+        r.set_mesh_accel(pkg.ACCEL_BVH)                      # asked for explicitly: taken
+        r.render(64, 48, 1, seed=1, camera=pkg.pinhole_camera())
+        assert r.last_kernel() == "mesh_bvh"
 
 
 @pytest.mark.gpu
