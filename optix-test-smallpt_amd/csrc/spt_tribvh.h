@@ -83,6 +83,14 @@
 #define SPT_THD inline
 #endif
 
+// The node tests are not the reference's arithmetic (tri_test is, and lives elsewhere): they may contract a * b + c into one fused operation
+// -- fewer VALU instructions, smaller rounding error; the thresholds' slack covers either form (the CPU harness runs the unfused one).
+#if defined(__clang__)
+#define SPT_TRI_FUSE _Pragma("clang fp contract(fast)")
+#else
+#define SPT_TRI_FUSE
+#endif
+
 namespace spt {
 
 constexpr double kTriBand = 1.0 / 8192.0;         // tau0 = M0 u, M0 = 2^11: (1) / (2) split at |nh.rdh| = kTriBand * g
@@ -116,6 +124,7 @@ SPT_THD float tri_sqrt(float x)
 
 SPT_THD void tri_query(float ox, float oy, float oz, float dx, float dy, float dz, TriQuery& q)
 {
+    SPT_TRI_FUSE
     const float inv = tri_rsq(dx * dx + dy * dy + dz * dz);
     q.o[0] = ox; q.o[1] = oy; q.o[2] = oz;
     q.h[0] = dx * inv; q.h[1] = dy * inv; q.h[2] = dz * inv;
@@ -127,6 +136,7 @@ SPT_THD void tri_query(float ox, float oy, float oz, float dx, float dy, float d
 // An empty child has kappa = -1e30.  Float evaluation: a.w = a.dp - s (a.rdh) and |w|^2 = |dp|^2 - s^2 cancel: both sides carry 16 u |dp|.
 SPT_THD bool tri_plane_child(const TriQuery& q, float ax, float ay, float az, float kappa, float px, float py, float pz, float sigma, float tau, float te)
 {
+    SPT_TRI_FUSE
     const float ah = ax * q.h[0] + ay * q.h[1] + az * q.h[2];
     const float dx = px - q.o[0], dy = py - q.o[1], dz = pz - q.o[2];
     const float s = dx * q.h[0] + dy * q.h[1] + dz * q.h[2];
@@ -144,6 +154,7 @@ SPT_THD bool tri_plane_child(const TriQuery& q, float ax, float ay, float az, fl
 //   |a.m| <= kappa |m| + lam + 32 u |dp|        (8.1 u |dp| of the bound, the rest for the float cross product)
 SPT_THD bool tri_line_child(const TriQuery& q, float ax, float ay, float az, float kappa, float px, float py, float pz, float lam)
 {
+    SPT_TRI_FUSE
     const float dx = px - q.o[0], dy = py - q.o[1], dz = pz - q.o[2];
     const float mx = dy * q.h[2] - dz * q.h[1], my = dz * q.h[0] - dx * q.h[2], mz = dx * q.h[1] - dy * q.h[0];
     const float am = ax * mx + ay * my + az * mz;
@@ -160,6 +171,7 @@ template <bool EXACT>
 SPT_THD bool tri_box_child(float l0x, float l1x, float l0y, float l1y, float l0z, float l1z, float ivx, float ivy, float ivz, float tcut,
                            float hx, float hy, float hz, float ax, float ay, float az, float kappa, float iq, float ee, float& tn)
 {
+    SPT_TRI_FUSE
     float p = 0.0f;
     if (EXACT) {
         const float mx = __builtin_fmaxf(__builtin_fabsf(l0x), __builtin_fabsf(l1x));
@@ -287,6 +299,7 @@ typedef const float4 tri_flat_t;
 template <class Stack, class Cand>
 SPT_THD void tri_scan_lines(const float4* __restrict__ flat_, const uint32_t* __restrict__ index_, uint32_t nslots, const TriQuery& q, Stack& st, Cand&& cand)
 {
+    SPT_TRI_FUSE
     tri_flat_t* flat = (tri_flat_t*)flat_;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __attribute__((address_space(4))) uint32_t* index = (const __attribute__((address_space(4))) uint32_t*)index_;
